@@ -1,0 +1,167 @@
+/*
+ * include/seqalign_hip.h -- C ABI of libseqalign_hip.so (MI355X / gfx950).
+ *
+ * Drop-in device boundary for the all-vs-all alignment hot path of
+ * jakovdev/SequenceAligner.  Plain C: pointers, sizes and PODs only, no C++ or
+ * torch types.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference repository root).
+ *
+ * The reference keeps scoring state in process globals (GAP_PEN/GAP_OPN/GAP_EXT,
+ * SEQ_LUT, SUB_MAT, ALIGN -- src/bio/align.h:11-19,28-42) and pushes it to the
+ * device through the `pC` symbol (src/bio/kernels.cuh:12-25).  Here the same
+ * state travels explicitly in `struct sa_scoring`; INTEGRATION.md shows the
+ * five-line adapter that fills it from the reference's globals.
+ *
+ * Failure model: like the reference's CALLR/perr (src/interface/seqalign_cuda.c:23-30)
+ * every call reports failure through its return value and leaves a human
+ * readable message retrievable with sa_last_error() (also printed on stderr
+ * when SA_HIP_VERBOSE is set).  There is NO CPU fallback anywhere behind this
+ * ABI: no HIP device (or a missing code object) is an error, never a silent
+ * host computation.
+ */
+#ifndef SEQALIGN_HIP_H
+#define SEQALIGN_HIP_H
+
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_ABI_VERSION 1
+
+/* ---- data types shared with the reference ------------------------------- */
+
+/* src/bio/align.h:6-9  `struct meta` (byte offset into the blob, length w/o NUL) */
+struct sa_meta {
+	int32_t off;
+	int32_t len;
+};
+
+/* src/io/input.h:6-11  `struct input`: one blob of uppercase residues, every
+ * sequence NUL-terminated; meta[k] locates sequence k; max = longest len. */
+struct sa_input {
+	uint8_t *seqs;
+	struct sa_meta *meta;
+	int32_t max;
+	int32_t num;
+};
+
+/* src/io/output.h:10-15  `struct output`.  matrix may be NULL (-W: compute,
+ * copy nothing; src/interface/seqalign_cuda.c:233,268,279).
+ * triangular: pair (i<j) at matrix[j*(j-1)/2 + i] (src/io/output.c:83);
+ * otherwise full dim x dim, matrix[dim*i+j] = matrix[dim*j+i] = score and the
+ * diagonal is left untouched (src/io/output.c:76-81). */
+struct sa_output {
+	int32_t *matrix;
+	const char **seqs;
+	size_t dim;
+	bool triangular;
+};
+
+/* Alignment methods = entries of the reference's `aligns` registry
+ * (src/bio/method/nw.c:46-51, ga.c:92-98, sw.c:66-71). */
+enum sa_method { SA_METHOD_NW = 0, SA_METHOD_GA = 1, SA_METHOD_SW = 2, SA_METHOD_COUNT = 3 };
+/* src/bio/align.h:34-37 */
+enum sa_gap_kind { SA_GAP_LINEAR = 0, SA_GAP_AFFINE = 1 };
+
+#define SA_LUT_SIZE 128 /* src/bio/align.h:11  SEQ_LUT_SIZE */
+#define SA_SUB_DIM 24   /* src/bio/align.h:13  SUB_MAT_DIM  */
+#define SA_SCORE_MIN (INT32_MIN / 2) /* src/bio/align.h:19 */
+
+/* Replaces the globals read by cuda_align (src/interface/seqalign_cuda.c:115-123,170).
+ * Gap values are the STORED form, i.e. already negated (src/bio/align.c:127-128):
+ * `-p 4` -> gap_pen = -4; `-s 10 -e 1` -> gap_opn = -10, gap_ext = -1. */
+struct sa_scoring {
+	int32_t method;                        /* enum sa_method                   (ALIGN)    */
+	int32_t gap_pen;                       /* linear gap, used by NW           (GAP_PEN)  */
+	int32_t gap_opn;                       /* affine open, used by GA and SW   (GAP_OPN)  */
+	int32_t gap_ext;                       /* affine extend, used by GA and SW (GAP_EXT)  */
+	int32_t lut[SA_LUT_SIZE];              /* ASCII -> 0..23, -1 invalid       (SEQ_LUT)  */
+	int32_t sub[SA_SUB_DIM * SA_SUB_DIM];  /* row-major 24x24                  (SUB_MAT)  */
+};
+
+/* ---- the two reference entry points ------------------------------------- */
+
+/* Replaces `bool cuda_memory(size_t bytes)` (src/interface/seqalign_cuda.h:7,
+ * src/interface/seqalign_cuda.c:71-93): true iff the device has bytes*4/3 free.
+ * Caller: output_load (src/io/output.c:37) to choose full vs triangular. */
+bool sa_hip_memory(size_t bytes);
+
+/* Replaces `bool cuda_align(struct input, struct output)`
+ * (src/interface/seqalign_cuda.h:9, src/interface/seqalign_cuda.c:95-296).
+ * Aligns every pair i<j of `in` and fills out.matrix in the layout out.triangular
+ * selects.  Caller owns in/out for the duration of the call; all device memory
+ * is allocated and released inside.  Uses every visible device when
+ * SA_HIP_DEVICES is unset (pair space range-partitioned, each device copies its
+ * slice straight into out.matrix), or the first n with SA_HIP_DEVICES=n. */
+bool sa_hip_align(struct sa_input in, struct sa_output out, const struct sa_scoring *sc);
+
+/* ---- device-resident layer (what sa_hip_align is built from) -------------
+ * Used by multi-process drivers (one process per GPU + RCCL all-gather of the
+ * packed slices, bench.py) and by callers that keep results in HBM. */
+
+typedef struct sa_ctx sa_ctx;
+
+/* Uploads the sequence store + scoring tables to `device` and plans the run
+ * (src/interface/seqalign_cuda.c:115-132,168).  NULL on failure. */
+sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa_scoring *sc);
+void sa_ctx_destroy(sa_ctx *ctx);
+
+/* N(N-1)/2 (src/util/macros.h:13 `alignments`) */
+int64_t sa_ctx_pairs(const sa_ctx *ctx);
+
+/* Scores of packed pair indices [start, start+count) into DEVICE memory
+ * d_scores[0..count) (= the reference's `kernel(scores, start, batch)`,
+ * src/bio/align.h:48, src/bio/kernels.cu:32-40,73).  Asynchronous on `stream`
+ * (a hipStream_t, NULL = default stream). 0 on success. */
+int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream);
+
+/* Packed triangular (device) -> full symmetric dim x dim with zero diagonal
+ * (device), the layout of src/io/output.c:76-81.  Asynchronous on `stream`. */
+int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t *d_full, void *stream);
+
+/* ---- pair-space planning (host only, no device needed) -------------------
+ * DP cells (sum of len_i*len_j) of the packed pair range [start, start+count),
+ * the numerator of GCUPS; -1 on a bad range. */
+int64_t sa_pairs_cells(const struct sa_meta *meta, int32_t num, int64_t start, int64_t count);
+/* Splits [0, N(N-1)/2) into `parts` contiguous ranges of near-equal DP work
+ * (cells); bounds[parts+1] receives the cut points (bounds[0]=0,
+ * bounds[parts]=pairs).  Multi-GPU sharding rule, SURVEY.md §8(e): the
+ * reference's own batch abstraction kernel(scores, start, batch) is a range. */
+int sa_pairs_partition(const struct sa_meta *meta, int32_t num, int parts, int64_t *bounds);
+
+/* Instrumentation for bench.py: name / launch count / accumulated HIP-event
+ * milliseconds of the dominant kernel since the last reset (events are
+ * recorded on the launch stream only while timing is enabled). */
+void sa_ctx_timing(sa_ctx *ctx, int enable);
+int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64_t *launches, double *total_ms);
+
+/* ---- option tables (host only, no device needed) ------------------------ */
+
+/* Replaces parse_matrix (src/bio/matrices.c:44-58): case-insensitive name ->
+ * SEQ_LUT + SUB_MAT.  0 on success. */
+int sa_matrix_load(const char *name, int32_t lut[SA_LUT_SIZE], int32_t sub[SA_SUB_DIM * SA_SUB_DIM]);
+/* -l / list_matrices (src/bio/matrices.c:27-33) */
+int sa_matrix_count(void);
+const char *sa_matrix_name(int index);
+int sa_matrix_is_nucleotide(int index);
+
+/* Replaces parse_align (src/bio/align.c:87-96): alias ("nw", "Needleman-Wunsch",
+ * ... case-insensitive) -> enum sa_method, -1 if unknown. */
+int sa_method_parse(const char *alias);
+const char *sa_method_name(int method);   /* long alias, e.g. "Gotoh"       */
+int sa_method_gap_kind(int method);       /* enum sa_gap_kind               */
+
+/* ---- misc ---------------------------------------------------------------- */
+int sa_hip_device_count(void);
+const char *sa_hip_device_name(int device);
+const char *sa_last_error(void);
+int sa_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQALIGN_HIP_H */

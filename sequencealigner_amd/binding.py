@@ -1,0 +1,337 @@
+"""ctypes binding of include/seqalign_hip.h (no torch dependency; torch is only plumbing for callers)."""
+from __future__ import annotations
+
+import ctypes as C
+import pathlib
+from dataclasses import dataclass, field
+from typing import Iterable, Optional, Sequence
+
+import numpy as np
+
+_LIB_PATH = pathlib.Path(__file__).resolve().parent / "lib" / "libseqalign_hip.so"
+_lib: Optional[C.CDLL] = None
+
+LUT_SIZE = 128
+SUB_DIM = 24
+SCORE_MIN = -(1 << 30)  # reference src/bio/align.h:19
+
+METHOD_NW, METHOD_GA, METHOD_SW = 0, 1, 2
+GAP_LINEAR, GAP_AFFINE = 0, 1
+
+
+class AlignError(RuntimeError):
+    """A call through the C ABI returned failure (message = sa_last_error())."""
+
+
+class _Meta(C.Structure):  # struct sa_meta  <- reference src/bio/align.h:6-9
+    _fields_ = [("off", C.c_int32), ("len", C.c_int32)]
+
+
+class _Input(C.Structure):  # struct sa_input <- reference src/io/input.h:6-11
+    _fields_ = [("seqs", C.c_void_p), ("meta", C.c_void_p), ("max", C.c_int32), ("num", C.c_int32)]
+
+
+class _Output(C.Structure):  # struct sa_output <- reference src/io/output.h:10-15
+    _fields_ = [("matrix", C.c_void_p), ("seqs", C.c_void_p), ("dim", C.c_size_t), ("triangular", C.c_bool)]
+
+
+class _Scoring(C.Structure):  # struct sa_scoring
+    _fields_ = [("method", C.c_int32), ("gap_pen", C.c_int32), ("gap_opn", C.c_int32), ("gap_ext", C.c_int32),
+                ("lut", C.c_int32 * LUT_SIZE), ("sub", C.c_int32 * (SUB_DIM * SUB_DIM))]
+
+
+#: every symbol include/seqalign_hip.h declares (tests check the .so exports exactly these)
+ABI_SYMBOLS = (
+    "sa_hip_memory", "sa_hip_align", "sa_ctx_create", "sa_ctx_destroy", "sa_ctx_pairs", "sa_pairs_cells",
+    "sa_ctx_align_range", "sa_ctx_expand_full", "sa_pairs_partition", "sa_ctx_timing", "sa_ctx_timing_read",
+    "sa_matrix_load", "sa_matrix_count", "sa_matrix_name", "sa_matrix_is_nucleotide", "sa_method_parse",
+    "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
+    "sa_abi_version",
+)
+
+
+def library_path() -> pathlib.Path:
+    return _LIB_PATH
+
+
+def load_library() -> C.CDLL:
+    """Load libseqalign_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not _LIB_PATH.exists():
+        raise AlignError(f"{_LIB_PATH} is missing: run `python __graft_entry__.py` (hipcc, gfx950) first; "
+                         "there is no CPU fallback")
+    lib = C.CDLL(str(_LIB_PATH))
+    lib.sa_hip_memory.argtypes = [C.c_size_t]
+    lib.sa_hip_memory.restype = C.c_bool
+    lib.sa_hip_align.argtypes = [_Input, _Output, C.POINTER(_Scoring)]
+    lib.sa_hip_align.restype = C.c_bool
+    lib.sa_ctx_create.argtypes = [C.c_int, _Input, C.POINTER(_Scoring)]
+    lib.sa_ctx_create.restype = C.c_void_p
+    lib.sa_ctx_destroy.argtypes = [C.c_void_p]
+    lib.sa_ctx_destroy.restype = None
+    lib.sa_ctx_pairs.argtypes = [C.c_void_p]
+    lib.sa_ctx_pairs.restype = C.c_int64
+    lib.sa_pairs_cells.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int64]
+    lib.sa_pairs_cells.restype = C.c_int64
+    lib.sa_ctx_align_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sa_ctx_align_range.restype = C.c_int
+    lib.sa_ctx_expand_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.sa_ctx_expand_full.restype = C.c_int
+    lib.sa_pairs_partition.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.POINTER(C.c_int64)]
+    lib.sa_pairs_partition.restype = C.c_int
+    lib.sa_ctx_timing.argtypes = [C.c_void_p, C.c_int]
+    lib.sa_ctx_timing.restype = None
+    lib.sa_ctx_timing_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.sa_ctx_timing_read.restype = C.c_int
+    lib.sa_matrix_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.sa_matrix_load.restype = C.c_int
+    lib.sa_matrix_count.restype = C.c_int
+    lib.sa_matrix_name.argtypes = [C.c_int]
+    lib.sa_matrix_name.restype = C.c_char_p
+    lib.sa_matrix_is_nucleotide.argtypes = [C.c_int]
+    lib.sa_matrix_is_nucleotide.restype = C.c_int
+    lib.sa_method_parse.argtypes = [C.c_char_p]
+    lib.sa_method_parse.restype = C.c_int
+    lib.sa_method_name.argtypes = [C.c_int]
+    lib.sa_method_name.restype = C.c_char_p
+    lib.sa_method_gap_kind.argtypes = [C.c_int]
+    lib.sa_method_gap_kind.restype = C.c_int
+    lib.sa_hip_device_count.restype = C.c_int
+    lib.sa_hip_device_name.argtypes = [C.c_int]
+    lib.sa_hip_device_name.restype = C.c_char_p
+    lib.sa_last_error.restype = C.c_char_p
+    lib.sa_abi_version.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _err() -> str:
+    return (load_library().sa_last_error() or b"").decode(errors="replace")
+
+
+def device_count() -> int:
+    return int(load_library().sa_hip_device_count())
+
+
+def device_name(device: int = 0) -> str:
+    name = load_library().sa_hip_device_name(device)
+    if not name:
+        raise AlignError(f"no HIP device {device}")
+    return name.decode()
+
+
+def matrix_names() -> list[str]:
+    lib = load_library()
+    return [lib.sa_matrix_name(k).decode() for k in range(lib.sa_matrix_count())]
+
+
+def method_names() -> list[str]:
+    lib = load_library()
+    return [lib.sa_method_name(k).decode() for k in range(3)]
+
+
+def pair_count(n: int) -> int:
+    """reference src/util/macros.h:13 `alignments(n)`"""
+    return n * (n - 1) // 2
+
+
+# --------------------------------------------------------------------------------------------
+@dataclass
+class SequenceStore:
+    """The reference's `struct input` (src/io/input.h:6-11): one NUL-separated uppercase blob + meta[]."""
+    blob: np.ndarray            # uint8, sum(len+1) bytes
+    meta: np.ndarray            # int32 [num, 2] = (off, len)
+    num: int
+    max: int
+
+    @classmethod
+    def from_sequences(cls, seqs: Iterable[bytes | str]) -> "SequenceStore":
+        # what input_load builds after a parser ran (src/io/input.c:68-81): sequences back to back,
+        # each NUL-terminated; parsers upper-case residues (src/io/source/fasta.c:51)
+        items = [(s.encode() if isinstance(s, str) else bytes(s)).upper() for s in seqs]
+        lens = np.fromiter((len(s) for s in items), dtype=np.int64, count=len(items))
+        total = int(lens.sum()) + len(items)
+        if total > np.iinfo(np.int32).max:
+            raise AlignError("sequence store exceeds 2 GiB")
+        blob = np.frombuffer(b"\0".join(items) + b"\0", dtype=np.uint8).copy()
+        offs = np.zeros(len(items), dtype=np.int64)
+        if len(items):
+            offs[1:] = np.cumsum(lens[:-1] + 1)
+        meta = np.stack([offs, lens], axis=1).astype(np.int32)
+        return cls(blob=blob, meta=np.ascontiguousarray(meta), num=len(items), max=int(lens.max()) if len(items) else 0)
+
+    def sequence(self, k: int) -> bytes:
+        off, ln = self.meta[k]
+        return self.blob[off:off + ln].tobytes()
+
+    def select(self, keep: Sequence[int]) -> "SequenceStore":
+        return SequenceStore.from_sequences(self.sequence(int(k)) for k in keep)
+
+    def prefix(self, n: int) -> "SequenceStore":
+        return self.select(range(n))
+
+    def _as_c(self) -> _Input:
+        return _Input(self.blob.ctypes.data, self.meta.ctypes.data, self.max, self.num)
+
+    @property
+    def pairs(self) -> int:
+        return pair_count(self.num)
+
+    def cells(self, start: int = 0, count: Optional[int] = None) -> int:
+        """DP cells (sum len_i*len_j) of packed pair range [start, start+count) -- GCUPS numerator."""
+        count = self.pairs - start if count is None else count
+        v = int(load_library().sa_pairs_cells(self.meta.ctypes.data, self.num, start, count))
+        if v < 0:
+            raise AlignError("bad pair range")
+        return v
+
+    def partition(self, parts: int) -> list[int]:
+        """Cut points of `parts` contiguous packed-index ranges of near-equal DP work (multi-GPU sharding)."""
+        b = (C.c_int64 * (parts + 1))()
+        if load_library().sa_pairs_partition(self.meta.ctypes.data, self.num, parts, b):
+            raise AlignError(_err())
+        return list(b)
+
+
+@dataclass
+class Scoring:
+    """The reference's scoring globals (src/bio/align.h:11-19); gaps in STORED (negated) form."""
+    method: int
+    gap_pen: int = 0
+    gap_opn: int = 0
+    gap_ext: int = 0
+    lut: np.ndarray = field(default_factory=lambda: np.full(LUT_SIZE, -1, np.int32))
+    sub: np.ndarray = field(default_factory=lambda: np.zeros(SUB_DIM * SUB_DIM, np.int32))
+    matrix_name: str = ""
+
+    @classmethod
+    def from_names(cls, method: str, matrix: str, gap_pen: Optional[int] = None, gap_open: Optional[int] = None,
+                   gap_extend: Optional[int] = None, equal_affine_to_nw: bool = True) -> "Scoring":
+        """`-a METHOD -m MATRIX (-p N | -s N -e N)` with the reference's validation rules.
+
+        parse_align src/bio/align.c:87-96; parse_matrix src/bio/matrices.c:44-58; gap values are given
+        positive and stored negated (src/bio/align.c:127-128); -p only with a linear method, -s/-e only with
+        an affine one and both required (src/bio/align.c:130-142,170-201); Gotoh with open == extend becomes
+        NW with that penalty (validate_ga, src/bio/method/ga.c:70-88, the -F answer)."""
+        lib = load_library()
+        m = lib.sa_method_parse(method.encode())
+        if m < 0:
+            raise AlignError("Invalid alignment method")
+        lut = np.empty(LUT_SIZE, np.int32)
+        sub = np.empty(SUB_DIM * SUB_DIM, np.int32)
+        if lib.sa_matrix_load(matrix.encode(), lut.ctypes.data_as(C.POINTER(C.c_int32)),
+                              sub.ctypes.data_as(C.POINTER(C.c_int32))):
+            raise AlignError("Invalid substitution matrix name")
+        for name, v in (("gap_pen", gap_pen), ("gap_open", gap_open), ("gap_extend", gap_extend)):
+            if v is not None and not (0 <= int(v) <= 2**31 - 1):
+                raise AlignError("Gap values must be positive integers")
+        kind = lib.sa_method_gap_kind(m)
+        if kind == GAP_LINEAR:
+            if gap_open is not None or gap_extend is not None:
+                raise AlignError("Affine gaps cannot be set for non-affine methods")
+            if gap_pen is None:
+                raise AlignError("Linear gap penalty (-p) is required")
+            return cls(m, gap_pen=-int(gap_pen), lut=lut, sub=sub, matrix_name=matrix.lower())
+        if gap_pen is not None:
+            raise AlignError("Gap penalty cannot be set for non-linear methods")
+        if gap_open is None or gap_extend is None:
+            raise AlignError("Affine gap open (-s) and extend (-e) are required")
+        if m == METHOD_GA and gap_open == gap_extend and equal_affine_to_nw:
+            return cls(METHOD_NW, gap_pen=-int(gap_open), gap_opn=SCORE_MIN, gap_ext=SCORE_MIN, lut=lut, sub=sub,
+                       matrix_name=matrix.lower())
+        return cls(m, gap_opn=-int(gap_open), gap_ext=-int(gap_extend), lut=lut, sub=sub, matrix_name=matrix.lower())
+
+    @property
+    def method_name(self) -> str:
+        return ("nw", "ga", "sw")[self.method]
+
+    def _as_c(self) -> _Scoring:
+        s = _Scoring(self.method, self.gap_pen, self.gap_opn, self.gap_ext)
+        C.memmove(s.lut, np.ascontiguousarray(self.lut, np.int32).ctypes.data, 4 * LUT_SIZE)
+        C.memmove(s.sub, np.ascontiguousarray(self.sub, np.int32).ctypes.data, 4 * SUB_DIM * SUB_DIM)
+        return s
+
+
+# --------------------------------------------------------------------------------------------
+def hip_memory(nbytes: int) -> bool:
+    """`cuda_memory` replacement (reference src/interface/seqalign_cuda.c:71-93)."""
+    return bool(load_library().sa_hip_memory(int(nbytes)))
+
+
+def hip_align(store: SequenceStore, scoring: Scoring, triangular: bool = False, write: bool = True) -> Optional[np.ndarray]:
+    """`cuda_align` replacement (reference src/interface/seqalign_cuda.c:95-296).
+
+    Returns the host matrix the reference would hand to its writer: packed triangular
+    (pair i<j at j(j-1)/2+i) or full N x N symmetric with zero diagonal; None when write=False
+    (the reference's -W: compute, copy nothing)."""
+    lib = load_library()
+    n = store.num
+    matrix = None
+    if write:
+        matrix = np.zeros(pair_count(n) if triangular else n * n, dtype=np.int32)  # mmap zero-fill, output.c:55
+    out = _Output(matrix.ctypes.data if matrix is not None else None, None, n, bool(triangular))
+    sc = scoring._as_c()
+    if not lib.sa_hip_align(store._as_c(), out, C.byref(sc)):
+        raise AlignError(_err())
+    if matrix is None:
+        return None
+    return matrix if triangular else matrix.reshape(n, n)
+
+
+class Context:
+    """Device-resident layer (sa_ctx_*): sequences + scoring uploaded once, ranges of the packed pair
+    index computed into device buffers the caller owns (e.g. torch tensors)."""
+
+    def __init__(self, store: SequenceStore, scoring: Scoring, device: int = 0):
+        self._lib = load_library()
+        self._store = store  # keep host arrays alive
+        sc = scoring._as_c()
+        self._h = self._lib.sa_ctx_create(int(device), store._as_c(), C.byref(sc))
+        if not self._h:
+            raise AlignError(_err())
+        self.num = store.num
+        self.device = int(device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.sa_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def pairs(self) -> int:
+        return int(self._lib.sa_ctx_pairs(self._h))
+
+    def cells(self, start: int = 0, count: Optional[int] = None) -> int:
+        return self._store.cells(start, count)
+
+    def partition(self, parts: int) -> list[int]:
+        return self._store.partition(parts)
+
+    def align_range(self, start: int, count: int, d_scores_ptr: int, stream: int = 0) -> None:
+        if self._lib.sa_ctx_align_range(self._h, start, count, C.c_void_p(d_scores_ptr), C.c_void_p(stream)):
+            raise AlignError(_err())
+
+    def expand_full(self, d_packed_ptr: int, d_full_ptr: int, stream: int = 0) -> None:
+        if self._lib.sa_ctx_expand_full(self._h, C.c_void_p(d_packed_ptr), C.c_void_p(d_full_ptr), C.c_void_p(stream)):
+            raise AlignError(_err())
+
+    def timing(self, enable: bool) -> None:
+        self._lib.sa_ctx_timing(self._h, int(enable))
+
+    def timing_read(self) -> tuple[str, int, float]:
+        name = C.create_string_buffer(256)
+        launches = C.c_int64()
+        ms = C.c_double()
+        if self._lib.sa_ctx_timing_read(self._h, name, 256, C.byref(launches), C.byref(ms)):
+            raise AlignError(_err())
+        return name.value.decode(), int(launches.value), float(ms.value)

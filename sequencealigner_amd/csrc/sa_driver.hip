@@ -1,0 +1,604 @@
+/*
+ * sa_driver.hip -- host side of libseqalign_hip.so: device context, planning, batching.
+ *
+ * Replaces the reference's device driver src/interface/seqalign_cuda.c:
+ *   cuda_device_init :48-69   -> device_ready()
+ *   cuda_memory      :71-93   -> sa_hip_memory()
+ *   cuda_align       :95-296  -> sa_hip_align() on top of sa_ctx_create()/sa_ctx_align_range()
+ * Differences by design: scoring state is passed explicitly (struct sa_scoring) instead of
+ * process globals; sequences are uploaded pre-encoded (residue index per byte) so no kernel
+ * ever touches the ASCII->index table; there is no CPU fallback.
+ */
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+#include "sa_internal.h"
+
+struct sa_ctx {
+	int device = 0;
+	int32_t num = 0, max_len = 0;
+	int64_t pairs = 0;
+	sa_scoring sc{};
+	std::vector<sa_meta> meta;
+	uint8_t *d_codes = nullptr;
+	sa_meta *d_meta = nullptr;
+	int32_t *d_sub = nullptr;
+	int32_t *d_scratch = nullptr;
+	int64_t scratch_stride = 0;
+	int generic_blocks = 0;
+	/* instrumentation */
+	bool timing = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+	std::string kernel_name;
+	int64_t launches = 0;
+};
+
+static bool device_ready(int device)
+{
+	int count = 0;
+	hipError_t err = hipGetDeviceCount(&count);
+	if (err != hipSuccess || count <= 0) {
+		sa_set_error("No HIP devices available (%s); libseqalign_hip has no CPU fallback",
+			     err == hipSuccess ? "device count is 0" : hipGetErrorString(err));
+		return false;
+	}
+	if (device < 0 || device >= count) {
+		sa_set_error("HIP device %d out of range (%d visible)", device, count);
+		return false;
+	}
+	SA_HIP_CHECK(hipSetDevice(device), return false);
+	return true;
+}
+
+extern "C" int sa_hip_device_count(void)
+{
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess)
+		return 0;
+	return count;
+}
+
+extern "C" const char *sa_hip_device_name(int device)
+{
+	static thread_local char name[256];
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+		return nullptr;
+	snprintf(name, sizeof(name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+	return name;
+}
+
+/* reference src/interface/seqalign_cuda.c:71-93 */
+extern "C" bool sa_hip_memory(size_t bytes)
+{
+	if (!device_ready(0))
+		return false;
+	size_t free_b = 0, total_b = 0;
+	SA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b), return false);
+	const long double need = (long double)bytes * 4.0L / 3.0L;
+	if ((long double)free_b < need) {
+		sa_set_error("%.2f GiB exceeds available GPU memory (%.2f GiB free)",
+			     (double)(need / (1 << 30)), (double)free_b / (double)(1 << 30));
+		return false;
+	}
+	return true;
+}
+
+/* ---- context ------------------------------------------------------------- */
+
+static bool validate_and_encode(const sa_input &in, const sa_scoring &sc, std::vector<uint8_t> &codes,
+				int32_t &max_len)
+{
+	if (!in.seqs || !in.meta) {
+		sa_set_error("sa_input: null sequence store");
+		return false;
+	}
+	if (in.num < 2) { /* reference src/bio/align.h:21, src/io/input.c:63 */
+		sa_set_error("Not enough sequences: %d (min: 2)", in.num);
+		return false;
+	}
+	if (sc.method < 0 || sc.method >= SA_METHOD_COUNT) {
+		sa_set_error("Invalid alignment method id %d", sc.method);
+		return false;
+	}
+	int64_t end = 0;
+	max_len = 0;
+	for (int32_t k = 0; k < in.num; k++) {
+		const sa_meta m = in.meta[k];
+		if (m.len < 1 || m.off < 0) { /* src/bio/align.h:22,25 */
+			sa_set_error("Sequence #%d has invalid offset/length (%d/%d)", k + 1, m.off, m.len);
+			return false;
+		}
+		end = std::max<int64_t>(end, (int64_t)m.off + m.len + 1);
+		max_len = std::max(max_len, m.len);
+	}
+	if (end > INT32_MAX) { /* src/io/source/fasta.c:73 */
+		sa_set_error("Sequence store exceeds 2 GiB");
+		return false;
+	}
+	codes.assign((size_t)end, (uint8_t)SA_CODE_SEP);
+	for (int32_t k = 0; k < in.num; k++) {
+		const sa_meta m = in.meta[k];
+		const uint8_t *s = in.seqs + m.off;
+		for (int32_t p = 0; p < m.len; p++) {
+			const uint8_t ch = s[p];
+			const int32_t idx = ch < SA_LUT_SIZE ? sc.lut[ch] : -1;
+			if (idx < 0 || idx >= SA_SUB_DIM) { /* parsers reject these: src/io/source/fasta.c:57-63 */
+				sa_set_error("Invalid character 0x%02x in sequence #%d at position %d", ch, k + 1, p + 1);
+				return false;
+			}
+			codes[(size_t)m.off + p] = (uint8_t)idx;
+		}
+		if (s[m.len] != 0) {
+			sa_set_error("Sequence #%d is not NUL-terminated at its recorded length", k + 1);
+			return false;
+		}
+	}
+	/* 32-bit safety: the reference computes in s32 and is undefined once a border, a sentinel
+	 * plus a gap, or a cell wraps.  Refuse such parameter/length combinations loudly. */
+	int64_t amax = 0, smax = 0;
+	if (sc.method == SA_METHOD_NW)
+		amax = std::llabs((int64_t)sc.gap_pen);
+	else
+		amax = std::max(std::llabs((int64_t)sc.gap_opn), std::llabs((int64_t)sc.gap_ext));
+	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++)
+		smax = std::max<int64_t>(smax, std::llabs((int64_t)sc.sub[k]));
+	const __int128 bound = (__int128)(2 * (int64_t)max_len + 3) * amax + (__int128)max_len * smax;
+	if (bound >= ((__int128)1 << 30)) {
+		sa_set_error("Gap penalty %lld with sequence length %d overflows 32-bit scores "
+			     "(undefined in the reference as well)", (long long)amax, max_len);
+		return false;
+	}
+	return true;
+}
+
+extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa_scoring *sc)
+{
+	if (!sc) {
+		sa_set_error("sa_ctx_create: null scoring");
+		return nullptr;
+	}
+	std::vector<uint8_t> codes;
+	int32_t max_len = 0;
+	if (!validate_and_encode(in, *sc, codes, max_len))
+		return nullptr;
+	if (!device_ready(device))
+		return nullptr;
+
+	sa_ctx *ctx = new sa_ctx();
+	ctx->device = device;
+	ctx->num = in.num;
+	ctx->max_len = max_len;
+	ctx->pairs = (int64_t)in.num * (in.num - 1) / 2;
+	ctx->sc = *sc;
+	ctx->meta.assign(in.meta, in.meta + in.num);
+
+	bool ok = false;
+	do {
+		SA_HIP_CHECK(hipMalloc(&ctx->d_codes, codes.size()), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_meta, sizeof(sa_meta) * (size_t)in.num), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_sub, sizeof(sc->sub)), break);
+		SA_HIP_CHECK(hipMemcpy(ctx->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(ctx->d_meta, in.meta, sizeof(sa_meta) * (size_t)in.num, hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(ctx->d_sub, sc->sub, sizeof(sc->sub), hipMemcpyHostToDevice), break);
+
+		/* strip-boundary scratch of the pair-per-wave kernels: 2*(max+2) ints per resident wave */
+		hipDeviceProp_t prop;
+		SA_HIP_CHECK(hipGetDeviceProperties(&prop, device), break);
+		ctx->scratch_stride = 2 * ((int64_t)max_len + 2);
+		int64_t blocks = (int64_t)prop.multiProcessorCount * 8;
+		const int64_t budget = (int64_t)1 << 30; /* 1 GiB */
+		const int64_t per_block = ctx->scratch_stride * 4 * (int64_t)sizeof(int32_t);
+		blocks = std::max<int64_t>(prop.multiProcessorCount, std::min(blocks, budget / per_block));
+		ctx->generic_blocks = (int)blocks;
+		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
+		ok = true;
+	} while (0);
+	if (!ok) {
+		sa_ctx_destroy(ctx);
+		return nullptr;
+	}
+	return ctx;
+}
+
+extern "C" void sa_ctx_destroy(sa_ctx *ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	for (auto &ev : ctx->events) {
+		(void)hipEventDestroy(ev.first);
+		(void)hipEventDestroy(ev.second);
+	}
+	(void)hipFree(ctx->d_codes);
+	(void)hipFree(ctx->d_meta);
+	(void)hipFree(ctx->d_sub);
+	(void)hipFree(ctx->d_scratch);
+	delete ctx;
+}
+
+extern "C" int64_t sa_ctx_pairs(const sa_ctx *ctx) { return ctx ? ctx->pairs : -1; }
+
+/* j of packed index p: largest j with j(j-1)/2 <= p */
+static int32_t column_of(int64_t p)
+{
+	int64_t j = (int64_t)((1.0 + std::sqrt(1.0 + 8.0 * (double)p)) * 0.5);
+	while (j * (j - 1) / 2 > p)
+		--j;
+	while ((j + 1) * j / 2 <= p)
+		++j;
+	return (int32_t)j;
+}
+
+/* ---- pair-space planning (host only) ---------------------------------------------------- */
+namespace {
+struct PairPlan {
+	int32_t num = 0;
+	int64_t pairs = 0;
+	const sa_meta *meta = nullptr;
+	std::vector<int64_t> len_prefix;  /* P[k] = sum_{i<k} len_i            (k = 0..N) */
+	std::vector<int64_t> cell_prefix; /* C[j] = sum_{j'<j} len_j' * P[j']  (j = 0..N) */
+
+	PairPlan(const sa_meta *m, int32_t n) : num(n), pairs((int64_t)n * (n - 1) / 2), meta(m)
+	{
+		len_prefix.assign((size_t)n + 1, 0);
+		cell_prefix.assign((size_t)n + 1, 0);
+		for (int32_t k = 0; k < n; k++) {
+			len_prefix[(size_t)k + 1] = len_prefix[(size_t)k] + m[k].len;
+			cell_prefix[(size_t)k + 1] = cell_prefix[(size_t)k] + (int64_t)m[k].len * len_prefix[(size_t)k];
+		}
+	}
+	/* DP cells of all pairs with packed index < p */
+	int64_t cells_before(int64_t p) const
+	{
+		if (p <= 0)
+			return 0;
+		if (p >= pairs)
+			return cell_prefix[(size_t)num];
+		const int32_t j = column_of(p);
+		const int64_t i = p - (int64_t)j * (j - 1) / 2;
+		return cell_prefix[(size_t)j] + (int64_t)meta[j].len * len_prefix[(size_t)i];
+	}
+};
+} // namespace
+
+extern "C" int64_t sa_pairs_cells(const struct sa_meta *meta, int32_t num, int64_t start, int64_t count)
+{
+	if (!meta || num < 2)
+		return -1;
+	PairPlan plan(meta, num);
+	if (start < 0 || count < 0 || start + count > plan.pairs)
+		return -1;
+	return plan.cells_before(start + count) - plan.cells_before(start);
+}
+
+extern "C" int sa_pairs_partition(const struct sa_meta *meta, int32_t num, int parts, int64_t *bounds)
+{
+	if (!meta || num < 2 || parts < 1 || !bounds) {
+		sa_set_error("sa_pairs_partition: bad arguments");
+		return 1;
+	}
+	PairPlan plan(meta, num);
+	const int64_t total = plan.cell_prefix[(size_t)num];
+	bounds[0] = 0;
+	for (int k = 1; k < parts; k++) {
+		const int64_t target = (int64_t)((__int128)total * k / parts);
+		int64_t lo = bounds[k - 1], hi = plan.pairs; /* first p with cells_before(p) >= target */
+		while (lo < hi) {
+			const int64_t mid = lo + (hi - lo) / 2;
+			if (plan.cells_before(mid) >= target)
+				hi = mid;
+			else
+				lo = mid + 1;
+		}
+		bounds[k] = lo;
+	}
+	bounds[parts] = plan.pairs;
+	return 0;
+}
+
+extern "C" void sa_ctx_timing(sa_ctx *ctx, int enable)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	for (auto &ev : ctx->events) {
+		(void)hipEventDestroy(ev.first);
+		(void)hipEventDestroy(ev.second);
+	}
+	ctx->events.clear();
+	ctx->launches = 0;
+	ctx->timing = enable != 0;
+}
+
+extern "C" int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64_t *launches, double *total_ms)
+{
+	if (!ctx)
+		return 1;
+	(void)hipSetDevice(ctx->device);
+	double ms = 0.0;
+	for (auto &ev : ctx->events) {
+		SA_HIP_CHECK(hipEventSynchronize(ev.second), return 1);
+		float t = 0.f;
+		SA_HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second), return 1);
+		ms += t;
+	}
+	if (kernel_name && cap > 0) {
+		strncpy(kernel_name, ctx->kernel_name.c_str(), (size_t)cap - 1);
+		kernel_name[cap - 1] = 0;
+	}
+	if (launches)
+		*launches = ctx->launches;
+	if (total_ms)
+		*total_ms = ms;
+	return 0;
+}
+
+extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream)
+{
+	if (!ctx || start < 0 || count < 0 || start + count > ctx->pairs || (!d_scores && count)) {
+		sa_set_error("sa_ctx_align_range: bad range [%lld,+%lld) of %lld pairs", (long long)start,
+			     (long long)count, ctx ? (long long)ctx->pairs : -1LL);
+		return 1;
+	}
+	if (count == 0)
+		return 0;
+	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
+	hipStream_t s = (hipStream_t)stream;
+
+	SaGenericArgs a{};
+	a.st.codes = ctx->d_codes;
+	a.st.meta = ctx->d_meta;
+	a.st.num = ctx->num;
+	a.sub = ctx->d_sub;
+	a.gap_pen = ctx->sc.gap_pen;
+	a.gap_opn = ctx->sc.gap_opn;
+	a.gap_ext = ctx->sc.gap_ext;
+	a.start = start;
+	a.count = count;
+	a.out = d_scores;
+	a.scratch = ctx->d_scratch;
+	a.scratch_stride = ctx->scratch_stride;
+	const int blocks = (int)std::min<int64_t>(ctx->generic_blocks, (count + 3) / 4);
+
+	hipEvent_t e0 = nullptr, e1 = nullptr;
+	if (ctx->timing) {
+		SA_HIP_CHECK(hipEventCreate(&e0), return 1);
+		SA_HIP_CHECK(hipEventCreate(&e1), return 1);
+		SA_HIP_CHECK(hipEventRecord(e0, s), return 1);
+	}
+	SA_HIP_CHECK(sa_launch_generic(ctx->sc.method, a, blocks, s), return 1);
+	if (ctx->timing) {
+		SA_HIP_CHECK(hipEventRecord(e1, s), return 1);
+		ctx->events.emplace_back(e0, e1);
+	}
+	ctx->kernel_name = sa_generic_kernel_name(ctx->sc.method);
+	ctx->launches++;
+	return 0;
+}
+
+extern "C" int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t *d_full, void *stream)
+{
+	if (!ctx || !d_packed || !d_full) {
+		sa_set_error("sa_ctx_expand_full: null argument");
+		return 1;
+	}
+	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
+	SA_HIP_CHECK(sa_launch_expand_full(d_packed, d_full, ctx->num, (hipStream_t)stream), return 1);
+	return 0;
+}
+
+/* ---- sa_hip_align: the cuda_align replacement (host buffers in, host matrix out) ---------- */
+
+namespace {
+
+constexpr int64_t BATCH_PAIRS = (int64_t)64 << 20; /* reference batch: src/interface/seqalign_cuda.c:136 */
+
+/* scatter a packed slice into the full symmetric host matrix (what output_fill does per column,
+ * reference src/io/output.c:76-81) */
+void host_scatter_full(int32_t *matrix, size_t dim, const int32_t *slice, int64_t start, int64_t count)
+{
+	int64_t p = start;
+	int64_t j = column_of(p);
+	int64_t i = p - j * (j - 1) / 2;
+	for (int64_t k = 0; k < count; k++) {
+		matrix[dim * (size_t)i + (size_t)j] = slice[k];
+		matrix[dim * (size_t)j + (size_t)i] = slice[k];
+		if (++i == j) {
+			i = 0;
+			++j;
+		}
+	}
+}
+
+/* one device: computes packed range [lo,hi) and delivers it to the host matrix */
+bool run_device_range(int device, const sa_input &in, const sa_output &out, const sa_scoring &sc, int64_t lo,
+		      int64_t hi, bool whole_job, std::string &err)
+{
+	sa_ctx *ctx = sa_ctx_create(device, in, &sc);
+	if (!ctx) {
+		err = sa_last_error();
+		return false;
+	}
+	bool ok = false;
+	int32_t *d_buf[2] = { nullptr, nullptr };
+	int32_t *d_full = nullptr;
+	int32_t *h_stage[2] = { nullptr, nullptr };
+	hipStream_t compute = nullptr, copy = nullptr;
+	hipEvent_t done[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
+	const int64_t total = hi - lo;
+	const size_t dim = (size_t)in.num;
+	do {
+		SA_HIP_CHECK(hipStreamCreate(&compute), break);
+		SA_HIP_CHECK(hipStreamCreate(&copy), break);
+		for (int k = 0; k < 2; k++) {
+			SA_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming), goto out);
+			SA_HIP_CHECK(hipEventCreateWithFlags(&copied[k], hipEventDisableTiming), goto out);
+		}
+		/* fast path for the full layout: whole job on this device and N^2 + packed fit in HBM */
+		if (!out.triangular && whole_job && out.matrix) {
+			size_t free_b = 0, total_b = 0;
+			SA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b), break);
+			const size_t need = sizeof(int32_t) * (dim * dim + (size_t)total);
+			if ((long double)need * 4 / 3 < (long double)free_b) {
+				SA_HIP_CHECK(hipMalloc(&d_buf[0], sizeof(int32_t) * (size_t)total), break);
+				SA_HIP_CHECK(hipMalloc(&d_full, sizeof(int32_t) * dim * dim), break);
+				if (sa_ctx_align_range(ctx, lo, total, d_buf[0], compute))
+					break;
+				if (sa_ctx_expand_full(ctx, d_buf[0], d_full, compute))
+					break;
+				SA_HIP_CHECK(hipMemcpyAsync(out.matrix, d_full, sizeof(int32_t) * dim * dim,
+							    hipMemcpyDeviceToHost, compute), break);
+				SA_HIP_CHECK(hipStreamSynchronize(compute), break);
+				ok = true;
+				break;
+			}
+		}
+		/* general path: double-buffered batches of packed scores */
+		const int64_t batch = std::min<int64_t>(std::max<int64_t>(total, 1), BATCH_PAIRS);
+		for (int k = 0; k < 2; k++) {
+			SA_HIP_CHECK(hipMalloc(&d_buf[k], sizeof(int32_t) * (size_t)batch), goto out);
+		}
+		if (out.matrix && !out.triangular) {
+			for (int k = 0; k < 2; k++) {
+				SA_HIP_CHECK(hipHostMalloc(&h_stage[k], sizeof(int32_t) * (size_t)batch), goto out);
+			}
+		}
+		{
+			int64_t issued = 0, delivered = 0;
+			int nb = 0;
+			struct Pending {
+				int64_t start, count;
+				int buf;
+			} pend[2];
+			int npend = 0;
+			bool failed = false;
+			auto deliver_oldest = [&]() -> bool {
+				Pending pd = pend[0];
+				SA_HIP_CHECK(hipEventSynchronize(copied[pd.buf]), return false);
+				if (out.matrix && !out.triangular)
+					host_scatter_full(out.matrix, dim, h_stage[pd.buf], pd.start, pd.count);
+				delivered += pd.count;
+				pend[0] = pend[1];
+				npend--;
+				return true;
+			};
+			while (issued < total && !failed) {
+				const int b = nb & 1;
+				if (npend == 2 && !deliver_oldest()) {
+					failed = true;
+					break;
+				}
+				const int64_t cnt = std::min(batch, total - issued);
+				if (sa_ctx_align_range(ctx, lo + issued, cnt, d_buf[b], compute)) {
+					failed = true;
+					break;
+				}
+				SA_HIP_CHECK(hipEventRecord(done[b], compute), failed = true; break);
+				SA_HIP_CHECK(hipStreamWaitEvent(copy, done[b], 0), failed = true; break);
+				if (out.matrix) {
+					int32_t *dst = out.triangular ? out.matrix + lo + issued : h_stage[b];
+					SA_HIP_CHECK(hipMemcpyAsync(dst, d_buf[b], sizeof(int32_t) * (size_t)cnt,
+								    hipMemcpyDeviceToHost, copy), failed = true; break);
+				}
+				SA_HIP_CHECK(hipEventRecord(copied[b], copy), failed = true; break);
+				/* the next kernel that reuses this buffer must wait for its copy-out */
+				SA_HIP_CHECK(hipStreamWaitEvent(compute, copied[b], 0), failed = true; break);
+				pend[npend++] = Pending{ lo + issued, cnt, b };
+				issued += cnt;
+				nb++;
+			}
+			while (!failed && npend)
+				if (!deliver_oldest())
+					failed = true;
+			if (failed)
+				break;
+			SA_HIP_CHECK(hipStreamSynchronize(compute), break);
+			SA_HIP_CHECK(hipStreamSynchronize(copy), break);
+			(void)delivered;
+		}
+		ok = true;
+	} while (0);
+out:
+	if (!ok)
+		err = sa_last_error();
+	for (int k = 0; k < 2; k++) {
+		if (d_buf[k])
+			(void)hipFree(d_buf[k]);
+		if (h_stage[k])
+			(void)hipHostFree(h_stage[k]);
+		if (done[k])
+			(void)hipEventDestroy(done[k]);
+		if (copied[k])
+			(void)hipEventDestroy(copied[k]);
+	}
+	if (d_full)
+		(void)hipFree(d_full);
+	if (compute)
+		(void)hipStreamDestroy(compute);
+	if (copy)
+		(void)hipStreamDestroy(copy);
+	sa_ctx_destroy(ctx);
+	return ok;
+}
+
+} // namespace
+
+extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const struct sa_scoring *sc)
+{
+	if (!sc) {
+		sa_set_error("sa_hip_align: null scoring");
+		return false;
+	}
+	if (out.matrix && out.dim != (size_t)in.num) {
+		sa_set_error("sa_hip_align: output dim %zu does not match %d sequences", out.dim, in.num);
+		return false;
+	}
+	int ndev = sa_hip_device_count();
+	if (ndev <= 0) {
+		sa_set_error("No HIP devices available; libseqalign_hip has no CPU fallback");
+		return false;
+	}
+	if (const char *env = getenv("SA_HIP_DEVICES")) {
+		const int want = atoi(env);
+		if (want >= 1 && want < ndev)
+			ndev = want;
+	}
+	const int64_t pairs = (int64_t)in.num * (in.num - 1) / 2;
+	if (pairs < (int64_t)ndev * 4096)
+		ndev = 1;
+	if (ndev == 1) {
+		std::string err;
+		if (!run_device_range(0, in, out, *sc, 0, pairs, true, err)) {
+			sa_set_error("%s", err.c_str());
+			return false;
+		}
+		return true;
+	}
+	/* several devices in one process: range-partition the packed index by DP work, one host
+	 * thread per device, every device delivers its slice straight into the host matrix */
+	std::vector<int64_t> bounds((size_t)ndev + 1);
+	if (sa_pairs_partition(in.meta, in.num, ndev, bounds.data()))
+		return false;
+	std::vector<std::thread> threads;
+	std::vector<std::string> errs((size_t)ndev);
+	std::vector<char> oks((size_t)ndev, 0);
+	for (int d = 0; d < ndev; d++)
+		threads.emplace_back([&, d]() {
+			oks[(size_t)d] = run_device_range(d, in, out, *sc, bounds[(size_t)d], bounds[(size_t)d + 1],
+							  false, errs[(size_t)d]);
+		});
+	for (auto &t : threads)
+		t.join();
+	for (int d = 0; d < ndev; d++)
+		if (!oks[(size_t)d]) {
+			sa_set_error("device %d: %s", d, errs[(size_t)d].c_str());
+			return false;
+		}
+	return true;
+}

@@ -1,0 +1,26 @@
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parents[1]
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "ref: needs the reference checkout at /root/reference (skipped elsewhere)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from tests.oracle_binding import Oracle
+    return Oracle()
+
+
+@pytest.fixture(scope="session")
+def sa():
+    import sequencealigner_amd
+    sequencealigner_amd.load_library()
+    return sequencealigner_amd

@@ -1,0 +1,158 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against
+  * the reference-generated golden vectors (tests/golden/),
+  * the CPU oracle on seeded random inputs,
+  * size-independent properties at BASELINE.json sizes (sampled oracle comparison, range additivity,
+    symmetry of the expanded matrix, row-permutation consistency).
+Bar: bit-exact (s32)."""
+import numpy as np
+import pytest
+
+from tests.golden_util import golden_cases, load_case, tri_to_full
+from tests.synth import make_config, make_dna_set, make_protein_set
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a visible HIP device"
+    return torch
+
+
+@pytest.mark.parametrize("name", golden_cases())
+def test_golden_through_c_abi(name, sa):
+    store, scoring, expected, full = load_case(name)
+    got = sa.hip_align(store, scoring, triangular=True)
+    assert np.array_equal(got, expected)
+    got_full = sa.hip_align(store, scoring, triangular=False)
+    assert np.array_equal(got_full, tri_to_full(expected, store.num))
+    if full is not None:
+        assert np.array_equal(got_full, full)
+
+
+RANDOM_CASES = [
+    ("nw", "blosum62", dict(gap_pen=4), "protein", 200, 1, 150),
+    ("nw", "blosum62", dict(gap_pen=0), "protein", 100, 1, 90),
+    ("nw", "pam250", dict(gap_pen=13), "protein", 100, 60, 200),
+    ("ga", "blosum62", dict(gap_open=10, gap_extend=1), "protein", 200, 1, 150),
+    ("ga", "blosum62", dict(gap_open=2, gap_extend=9), "protein", 100, 1, 100),
+    ("ga", "blosum45", dict(gap_open=0, gap_extend=3), "protein", 100, 1, 100),
+    ("sw", "blosum62", dict(gap_open=10, gap_extend=1), "protein", 200, 1, 150),
+    ("sw", "blosum62", dict(gap_open=0, gap_extend=0), "protein", 100, 1, 100),
+    ("sw", "nuc44", dict(gap_open=10, gap_extend=1), "dna", 150, 100, 200),
+    ("nw", "dnafull", dict(gap_pen=4), "dna", 100, 1, 300),
+    ("ga", "nuc44", dict(gap_open=12, gap_extend=3), "dna", 100, 120, 180),
+    ("nw", "blosum62", dict(gap_pen=100000), "protein", 60, 1, 120),
+    ("sw", "blosum62", dict(gap_open=50000, gap_extend=70000), "protein", 60, 1, 120),
+]
+
+
+@pytest.mark.parametrize("method,matrix,gaps,kind,n,lo,hi", RANDOM_CASES)
+def test_random_sets_against_oracle(method, matrix, gaps, kind, n, lo, hi, sa, oracle):
+    seqs = make_protein_set(n, lo, hi, 101) if kind == "protein" else make_dna_set(n, lo, hi, 102, iupac=True)
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(method, matrix, **gaps)
+    assert np.array_equal(sa.hip_align(store, scoring, triangular=True), oracle.align(store, scoring, triangular=True))
+
+
+def test_edge_shapes(sa, oracle):
+    """minimum job (2 sequences of length 1), ragged lengths, identical sequences, very long vs very short"""
+    scoring_all = [sa.Scoring.from_names("nw", "blosum62", gap_pen=4),
+                   sa.Scoring.from_names("ga", "blosum62", gap_open=10, gap_extend=1),
+                   sa.Scoring.from_names("sw", "blosum62", gap_open=10, gap_extend=1)]
+    sets = [
+        [b"A", b"W"],
+        [b"A", b"A"],
+        [b"ARNDCQEGHILKMFPSTWYVBZX*"] * 5,
+        [b"W" * 1, b"W" * 2000, b"A" * 3, b"ARND" * 300, b"W" * 65, b"W" * 64, b"W" * 63],
+        make_protein_set(3, 2500, 3000, 5) + [b"M"],
+    ]
+    for seqs in sets:
+        store = sa.SequenceStore.from_sequences(seqs)
+        for sc in scoring_all:
+            assert np.array_equal(sa.hip_align(store, sc, triangular=True), oracle.align(store, sc, triangular=True))
+            assert np.array_equal(sa.hip_align(store, sc, triangular=False), oracle.align(store, sc, triangular=False))
+
+
+def test_error_behaviour(sa):
+    sc = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
+    with pytest.raises(sa.AlignError, match="Not enough sequences"):
+        sa.hip_align(sa.SequenceStore.from_sequences([b"ARND"]), sc)
+    with pytest.raises(sa.AlignError, match="Invalid character"):
+        sa.hip_align(sa.SequenceStore.from_sequences([b"ARND", b"AJND"]), sc)  # J is not in the amino alphabet
+    with pytest.raises(sa.AlignError, match="overflows 32-bit"):
+        sa.hip_align(sa.SequenceStore.from_sequences([b"ARND" * 100, b"ARNW" * 100]),
+                     sa.Scoring.from_names("nw", "blosum62", gap_pen=2**31 - 1))
+    assert sa.hip_align(sa.SequenceStore.from_sequences([b"ARND", b"ARNW"]), sc, write=False) is None  # -W
+    assert sa.hip_memory(1 << 20) is True
+    assert sa.hip_memory(1 << 50) is False
+
+
+def test_device_resident_ranges(sa, oracle, torch_cuda):
+    """sa_ctx_align_range == the reference's kernel(scores, start, batch): any split of the packed index
+    gives the same scores; expand_full gives the symmetric zero-diagonal matrix."""
+    torch = torch_cuda
+    store = sa.SequenceStore.from_sequences(make_protein_set(300, 20, 130, 7))
+    for method, gaps in (("nw", dict(gap_pen=4)), ("ga", dict(gap_open=10, gap_extend=1)), ("sw", dict(gap_open=10, gap_extend=1))):
+        scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+        want = oracle.align(store, scoring, triangular=True)
+        with sa.Context(store, scoring, 0) as ctx:
+            assert ctx.pairs == want.size
+            out = torch.full((ctx.pairs,), -7, dtype=torch.int32, device="cuda")
+            stream = torch.cuda.current_stream().cuda_stream
+            cuts = [0, 1, 2, 65, 4097, 20000, ctx.pairs]
+            for a, b in zip(cuts, cuts[1:]):
+                ctx.align_range(a, b - a, out.data_ptr() + 4 * a, stream)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want)
+            full = torch.full((store.num, store.num), -9, dtype=torch.int32, device="cuda")
+            ctx.expand_full(out.data_ptr(), full.data_ptr(), stream)
+            torch.cuda.synchronize()
+            f = full.cpu().numpy()
+            assert np.array_equal(f, oracle.align(store, scoring, triangular=False))
+            assert np.array_equal(f, f.T) and not np.diag(f).any()
+            bounds = ctx.partition(4)
+            parts = []
+            for a, b in zip(bounds, bounds[1:]):
+                t = torch.empty(b - a, dtype=torch.int32, device="cuda")
+                ctx.align_range(a, b - a, t.data_ptr(), stream)
+                parts.append(t)
+            torch.cuda.synchronize()
+            assert np.array_equal(torch.cat(parts).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("cfg_name,n", [("cfg2", 10_000), ("cfg3", 10_000), ("cfg4", 6_000), ("cfg5", 6_000)])
+def test_baseline_sizes_sampled(cfg_name, n, sa, oracle, torch_cuda):
+    """BASELINE.json shapes (cfg 2/3 at full size; cfg 4/5 sequence shapes on a 6k subset that one GPU does in
+    seconds): 200k sampled pairs + one full column + the first 300-sequence block against the oracle, and a
+    checksum-of-checksums of a split run against the single-range run."""
+    torch = torch_cuda
+    seqs, cfg = make_config(cfg_name, n)
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    with sa.Context(store, scoring, 0) as ctx:
+        out = torch.empty(ctx.pairs, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.align_range(0, ctx.pairs, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy()
+        # (1) random sample
+        rng = np.random.default_rng(5)
+        idx = np.sort(rng.integers(0, ctx.pairs, 200_000))
+        assert np.array_equal(got[idx], oracle.align_pairs(store, scoring, idx))
+        # (2) last column (j = n-1) and first 300x300 block
+        j = store.num - 1
+        col = np.arange(j * (j - 1) // 2, j * (j - 1) // 2 + j)
+        assert np.array_equal(got[col], oracle.align_pairs(store, scoring, col))
+        blk = 300 * 299 // 2
+        assert np.array_equal(got[:blk], oracle.align_range(store, scoring, 0, blk))
+        # (3) split into 8 work-balanced ranges == single range (what the multi-GPU path relies on)
+        bounds = ctx.partition(8)
+        out2 = torch.empty_like(out)
+        for a, b in zip(bounds, bounds[1:]):
+            ctx.align_range(a, b - a, out2.data_ptr() + 4 * a, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2)
+        sums = [int(out2[a:b].to(torch.int64).sum()) for a, b in zip(bounds, bounds[1:])]
+        assert sum(sums) == int(got.astype(np.int64).sum())
