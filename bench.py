@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- all-vs-all alignment throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 5 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE pass of the hot path over the whole workload: every pair i<j of the synthetic
+sequence set is scored (NW/BLOSUM62/gap 4 for the headline config) into the packed
+upper-triangular vector resident in HBM.  With N>1 ranks the packed pair index is cut into N
+contiguous ranges (strong scaling: total work fixed), every rank scores its range, and ONE RCCL
+all-gather over xGMI assembles the full vector on every GPU -- that all-gather is inside the timed
+step.  Inputs are resident in HBM before the timed region.
+
+Printed JSON (rank 0): metric/value per the driver contract, plus
+  roofline     -- dominant kernel vs the HBM roof, live HIP-event timing on the launch stream
+  cpu_baseline -- the reference's own CPU path (oracle/_ref, kind "reference") or our C restatement
+                  (oracle/, kind "port") timed on this host's cores on a bounded sample
+  gcups, valu  -- the bound that actually constrains this integer DP
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import sequencealigner_amd as sa  # noqa: E402
+from sequencealigner_amd.distributed import gather_packed, rank_range  # noqa: E402
+from tests.synth import CONFIGS, make_config  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 s32 lane-ops/s
+OPS_PER_CELL = {"nw": 5, "ga": 9, "sw": 11}  # reference op counts (nw.c:29-35, ga.c:47-62, sw.c:39-57)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--n", type=int, default=None, help="override sequence count (parity/debug runs)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(seqs, cfg, target_s: float) -> dict:
+    """Reference CPU path on a bounded prefix of the same workload (pairs/s, all host cores)."""
+    from tests.oracle_binding import Oracle, RefLib, ref_available
+
+    ncores = os.cpu_count() or 1
+    oracle = Oracle()
+    threads = min(ncores, oracle.max_threads)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+
+    def run(n, use_ref):
+        store = sa.SequenceStore.from_sequences(seqs[:n])
+        if use_ref:
+            ref = RefLib(cfg["method"], cfg["matrix"], threads=threads, **cfg["gaps"])
+            try:
+                t = time.perf_counter()
+                ref.align(store, triangular=True)
+                return time.perf_counter() - t, store
+            finally:
+                ref.close()
+        t = time.perf_counter()
+        oracle.align(store, scoring, triangular=True, threads=threads)
+        return time.perf_counter() - t, store
+
+    use_ref = False
+    if ref_available():
+        try:
+            run(64, True)
+            use_ref = True
+        except Exception:
+            use_ref = False
+    n0 = min(len(seqs), 600)
+    t0, _ = run(n0, use_ref)
+    rate = (n0 * (n0 - 1) / 2) / max(t0, 1e-6)
+    n = int(min(len(seqs), max(n0, (2 * rate * target_s) ** 0.5)))
+    t, store = run(n, use_ref)
+    pairs = n * (n - 1) // 2
+    return {
+        "value": pairs / t, "unit": "pair-alignments/s", "cores": threads,
+        "kind": "reference" if use_ref else "port",
+        "sample": f"first {n} sequences of the workload = {pairs} pairs, {store.cells()} cells, {t:.2f} s",
+        "gcups": store.cells() / t / 1e9,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    seqs, cfg = make_config(args.config, args.n)
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    pairs = store.pairs
+    cells = store.cells()
+
+    # strong scaling: equal-count contiguous ranges, padded so the all-gather lands in place
+    per, lo, hi = rank_range(pairs, world, rank)
+    ctx = sa.Context(store, scoring, local_rank)
+    packed = torch.zeros(per * world, dtype=torch.int32, device="cuda")
+    mine = packed[rank * per:(rank + 1) * per]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.align_range(lo, hi - lo, mine.data_ptr(), stream)
+        if dist is not None:
+            gather_packed(dist, packed, rank, per)
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kname, launches, kernel_ms = ctx.timing_read()
+    ctx.timing(False)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # end-to-end through the host boundary (upload + kernels + D2H of the packed result), rank 0, N=1 only
+    e2e = None
+    if world == 1:
+        t1 = time.perf_counter()
+        host = sa.hip_align(store, scoring, triangular=True)
+        e2e = time.perf_counter() - t1
+        assert np.array_equal(host, packed[:pairs].cpu().numpy()), "host-boundary result differs from device-resident result"
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = pairs * args.steps / elapsed
+        # dominant kernel: algorithmic HBM bytes of ONE launch / its average duration
+        my_pairs = hi - lo
+        alg_bytes = 4 * my_pairs + int(store.blob.size) + 8 * store.num
+        avg_ms = kernel_ms / max(launches, 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        my_cells = store.cells(lo, hi - lo)
+        kernel_gcups = my_cells / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "pair-alignments/sec", "value": value, "unit": "pair-alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], "
+                                   f"{cfg['method']} {cfg['matrix']} {cfg['gaps']}, all-vs-all packed triangular",
+                       "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (" + RCCL all-gather" if world > 1 else "")},
+            "gcups": cells * args.steps / elapsed / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "kernel_avg_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
+            "valu": {"kernel_gcups": kernel_gcups, "reference_ops_per_cell": OPS_PER_CELL[scoring.method_name],
+                     "peak_lane_ops_per_s": VALU_LANE_OPS,
+                     "frac_of_valu_peak_at_reference_op_count": kernel_gcups * 1e9 * OPS_PER_CELL[scoring.method_name] / VALU_LANE_OPS},
+            "device": sa.device_name(local_rank),
+        }
+        if e2e is not None:
+            out["host_boundary"] = {"seconds": e2e, "pairs_per_s": pairs / e2e,
+                                    "note": "sa_hip_align: encode+upload+kernels+D2H into pageable host memory (PCIe-inclusive)"}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(seqs, cfg, args.cpu_seconds)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -2,7 +2,10 @@
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
+import os
 import pathlib
+import sys
 from dataclasses import dataclass, field
 from typing import Iterable, Optional, Sequence
 
@@ -54,6 +57,26 @@ def library_path() -> pathlib.Path:
     return _LIB_PATH
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships a private libamdhip64.so that its
+    libraries request by the un-versioned file name, so it does not unify with /opt/rocm's copy by
+    soname; two runtimes in one process leave the second without devices.  When torch is installed
+    but not imported yet, bring ITS runtime in first so that libseqalign_hip.so (NEEDED
+    libamdhip64.so.7) and a later `import torch` resolve to the same object.  A plain C host links
+    /opt/rocm's runtime and never sees this."""
+    if "torch" in sys.modules or os.environ.get("SA_HIP_NO_TORCH_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = pathlib.Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def load_library() -> C.CDLL:
     """Load libseqalign_hip.so (built in-tree by __graft_entry__.build()).  Fails loudly."""
     global _lib
@@ -62,6 +85,7 @@ def load_library() -> C.CDLL:
     if not _LIB_PATH.exists():
         raise AlignError(f"{_LIB_PATH} is missing: run `python __graft_entry__.py` (hipcc, gfx950) first; "
                          "there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     lib = C.CDLL(str(_LIB_PATH))
     lib.sa_hip_memory.argtypes = [C.c_size_t]
     lib.sa_hip_memory.restype = C.c_bool
