@@ -146,7 +146,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    kname, launches, kernel_ms = ctx.timing_read()
+    tm = ctx.timing_read()
     ctx.timing(False)
 
     if dist is not None:
@@ -165,13 +165,16 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = pairs * args.steps / elapsed
-        # dominant kernel: algorithmic HBM bytes of ONE launch / its average duration
-        my_pairs = hi - lo
-        alg_bytes = 4 * my_pairs + int(store.blob.size) + 8 * store.num
-        avg_ms = kernel_ms / max(launches, 1)
+        # dominant kernel: algorithmic HBM bytes of ONE launch (4 B per pair written + the
+        # sequence store and its offsets read once) / that kernel's average launch duration (HIP events)
+        launches = max(tm["launches"], 1)
+        k_pairs = tm["pairs"] // launches
+        k_cells = tm["cells"] // launches
+        alg_bytes = 4 * k_pairs + int(store.blob.size) + 8 * store.num
+        avg_ms = tm["ms"] / launches
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        my_cells = store.cells(lo, hi - lo)
-        kernel_gcups = my_cells / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kernel_gcups = k_cells / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        kname = tm["kernel"]
         out = {
             "metric": "pair-alignments/sec", "value": value, "unit": "pair-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -183,7 +186,8 @@ def main():
             "gcups": cells * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
-                         "kernel_avg_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": alg_bytes},
+                         "kernel_avg_ms": avg_ms, "launches": tm["launches"], "algorithmic_bytes_per_launch": alg_bytes,
+                         "pairs_per_launch": k_pairs, "all_kernels_ms_per_step": tm["all_kernels_ms"] / args.steps},
             "valu": {"kernel_gcups": kernel_gcups, "reference_ops_per_cell": OPS_PER_CELL[scoring.method_name],
                      "peak_lane_ops_per_s": VALU_LANE_OPS,
                      "frac_of_valu_peak_at_reference_op_count": kernel_gcups * 1e9 * OPS_PER_CELL[scoring.method_name] / VALU_LANE_OPS},

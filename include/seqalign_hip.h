@@ -133,11 +133,14 @@ int64_t sa_pairs_cells(const struct sa_meta *meta, int32_t num, int64_t start, i
  * reference's own batch abstraction kernel(scores, start, batch) is a range. */
 int sa_pairs_partition(const struct sa_meta *meta, int32_t num, int parts, int64_t *bounds);
 
-/* Instrumentation for bench.py: name / launch count / accumulated HIP-event
- * milliseconds of the dominant kernel since the last reset (events are
- * recorded on the launch stream only while timing is enabled). */
+/* Instrumentation for bench.py.  While enabled every kernel launch of
+ * sa_ctx_align_range is bracketed by a HIP-event pair on the launch stream.
+ * sa_ctx_timing_read reports the DOMINANT kernel (largest accumulated time)
+ * since the last enable: its name, launch count, accumulated milliseconds and
+ * the pairs / DP cells those launches covered, plus the sum over all kernels. */
 void sa_ctx_timing(sa_ctx *ctx, int enable);
-int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64_t *launches, double *total_ms);
+int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64_t *launches, double *total_ms,
+		       int64_t *pairs, int64_t *cells, double *all_kernels_ms);
 
 /* ---- option tables (host only, no device needed) ------------------------ */
 

@@ -107,7 +107,8 @@ def load_library() -> C.CDLL:
     lib.sa_pairs_partition.restype = C.c_int
     lib.sa_ctx_timing.argtypes = [C.c_void_p, C.c_int]
     lib.sa_ctx_timing.restype = None
-    lib.sa_ctx_timing_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    lib.sa_ctx_timing_read.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_double)]
     lib.sa_ctx_timing_read.restype = C.c_int
     lib.sa_matrix_load.argtypes = [C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.sa_matrix_load.restype = C.c_int
@@ -352,10 +353,13 @@ class Context:
     def timing(self, enable: bool) -> None:
         self._lib.sa_ctx_timing(self._h, int(enable))
 
-    def timing_read(self) -> tuple[str, int, float]:
+    def timing_read(self) -> dict:
+        """Dominant kernel since timing(True): name, launches, total ms, pairs and cells it covered."""
         name = C.create_string_buffer(256)
-        launches = C.c_int64()
-        ms = C.c_double()
-        if self._lib.sa_ctx_timing_read(self._h, name, 256, C.byref(launches), C.byref(ms)):
+        launches, pairs, cells = C.c_int64(), C.c_int64(), C.c_int64()
+        ms, all_ms = C.c_double(), C.c_double()
+        if self._lib.sa_ctx_timing_read(self._h, name, 256, C.byref(launches), C.byref(ms), C.byref(pairs),
+                                        C.byref(cells), C.byref(all_ms)):
             raise AlignError(_err())
-        return name.value.decode(), int(launches.value), float(ms.value)
+        return dict(kernel=name.value.decode(), launches=int(launches.value), ms=float(ms.value),
+                    pairs=int(pairs.value), cells=int(cells.value), all_kernels_ms=float(all_ms.value))

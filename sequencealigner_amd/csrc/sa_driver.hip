@@ -24,19 +24,50 @@ struct sa_ctx {
 	int32_t num = 0, max_len = 0;
 	int64_t pairs = 0;
 	sa_scoring sc{};
-	std::vector<sa_meta> meta;
+	std::vector<sa_meta> meta;     /* device-side (tight) layout: off[k] = sum_{i<k}(len_i+1)          */
+	std::vector<int32_t> off;      /* num+1 tight offsets                                                */
 	uint8_t *d_codes = nullptr;
 	sa_meta *d_meta = nullptr;
+	int32_t *d_off = nullptr;
 	int32_t *d_sub = nullptr;
+	int8_t *d_sub8 = nullptr;
 	int32_t *d_scratch = nullptr;
 	int64_t scratch_stride = 0;
 	int generic_blocks = 0;
-	/* instrumentation */
+	/* systolic fast path: parameters and validity (see systolic_setup) */
+	bool sys_ok = false;
+	int32_t sys_pconst = 0, sys_q = 0;
+	int64_t sys_gain = 0, sys_slack = 0;
+	/* launch plan of the most recent packed range (bench loops over the same range) */
+	struct ClassLaunch {
+		int cls = 0;
+		int32_t ncols = 0, ntiles = 0;
+		int64_t pairs = 0, cells = 0;
+		int32_t *d_jlist = nullptr, *d_tprefix = nullptr;
+	};
+	struct Plan {
+		int64_t start = -1, count = -1;
+		std::vector<ClassLaunch> classes;
+		std::vector<std::pair<int64_t, int64_t>> generic; /* (start, count) runs for the generic kernels */
+	} plan;
+	/* instrumentation: one HIP-event pair per kernel launch, keyed by kernel name */
 	bool timing = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-	std::string kernel_name;
-	int64_t launches = 0;
+	struct Timed {
+		std::string name;
+		hipEvent_t e0, e1;
+		int64_t pairs, cells;
+	};
+	std::vector<Timed> events;
 };
+
+static void plan_release(sa_ctx *ctx)
+{
+	for (auto &c : ctx->plan.classes) {
+		(void)hipFree(c.d_jlist);
+		(void)hipFree(c.d_tprefix);
+	}
+	ctx->plan = sa_ctx::Plan();
+}
 
 static bool device_ready(int device)
 {
@@ -92,7 +123,7 @@ extern "C" bool sa_hip_memory(size_t bytes)
 /* ---- context ------------------------------------------------------------- */
 
 static bool validate_and_encode(const sa_input &in, const sa_scoring &sc, std::vector<uint8_t> &codes,
-				int32_t &max_len)
+				std::vector<int32_t> &off, int32_t &max_len)
 {
 	if (!in.seqs || !in.meta) {
 		sa_set_error("sa_input: null sequence store");
@@ -106,21 +137,26 @@ static bool validate_and_encode(const sa_input &in, const sa_scoring &sc, std::v
 		sa_set_error("Invalid alignment method id %d", sc.method);
 		return false;
 	}
+	/* device layout is always tight (sequence, terminator, next sequence ...) whatever the
+	 * caller's offsets are: the systolic kernels stream this blob as their row input */
 	int64_t end = 0;
 	max_len = 0;
+	off.assign((size_t)in.num + 1, 0);
 	for (int32_t k = 0; k < in.num; k++) {
 		const sa_meta m = in.meta[k];
 		if (m.len < 1 || m.off < 0) { /* src/bio/align.h:22,25 */
 			sa_set_error("Sequence #%d has invalid offset/length (%d/%d)", k + 1, m.off, m.len);
 			return false;
 		}
-		end = std::max<int64_t>(end, (int64_t)m.off + m.len + 1);
+		off[(size_t)k] = (int32_t)end;
+		end += (int64_t)m.len + 1;
 		max_len = std::max(max_len, m.len);
+		if (end > INT32_MAX) { /* src/io/source/fasta.c:73 */
+			sa_set_error("Sequence store exceeds 2 GiB");
+			return false;
+		}
 	}
-	if (end > INT32_MAX) { /* src/io/source/fasta.c:73 */
-		sa_set_error("Sequence store exceeds 2 GiB");
-		return false;
-	}
+	off[(size_t)in.num] = (int32_t)end;
 	codes.assign((size_t)end, (uint8_t)SA_CODE_SEP);
 	for (int32_t k = 0; k < in.num; k++) {
 		const sa_meta m = in.meta[k];
@@ -132,7 +168,7 @@ static bool validate_and_encode(const sa_input &in, const sa_scoring &sc, std::v
 				sa_set_error("Invalid character 0x%02x in sequence #%d at position %d", ch, k + 1, p + 1);
 				return false;
 			}
-			codes[(size_t)m.off + p] = (uint8_t)idx;
+			codes[(size_t)off[(size_t)k] + p] = (uint8_t)idx;
 		}
 		if (s[m.len] != 0) {
 			sa_set_error("Sequence #%d is not NUL-terminated at its recorded length", k + 1);
@@ -157,6 +193,68 @@ static bool validate_and_encode(const sa_input &in, const sa_scoring &sc, std::v
 	return true;
 }
 
+/* Decides whether the systolic streaming kernels (sa_systolic.hip) reproduce the reference exactly
+ * for this scoring, and derives their constants.  Conditions (see that file's header):
+ *   - profile entries S + pconst (and the Gotoh first-column tweak) fit s8, -128 is reserved,
+ *   - Gotoh: q = open - extend <= 0 (|open| >= |extend|),
+ *   - the per-sequence baseline raise DELTA times the stream length stays far inside s32. */
+static void systolic_setup(sa_ctx *ctx)
+{
+	const sa_scoring &sc = ctx->sc;
+	int64_t smax = INT32_MIN, smin = INT32_MAX;
+	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++) {
+		smax = std::max<int64_t>(smax, sc.sub[k]);
+		smin = std::min<int64_t>(smin, sc.sub[k]);
+	}
+	ctx->sys_ok = false;
+	if (smin < -127 || smax > 127 || getenv("SA_HIP_FORCE_GENERIC"))
+		return;
+	int64_t pconst, q = 0, pmax, gain, slack;
+	const int64_t g = sc.gap_pen, o = sc.gap_opn, e = sc.gap_ext;
+	switch (sc.method) {
+	case SA_METHOD_NW:
+		pconst = -2 * g;
+		pmax = smax + pconst;
+		gain = std::max<int64_t>(0, smax - 2 * g);
+		slack = 2;
+		break;
+	case SA_METHOD_GA:
+		q = o - e;
+		if (q > 0)
+			return;
+		pconst = -e - o;
+		pmax = smax + pconst - q; /* first real column carries -q on top */
+		gain = std::max<int64_t>(0, smax - 2 * e);
+		slack = 2 * (-q) + 2;
+		break;
+	default:
+		pconst = -o;
+		pmax = smax + pconst;
+		gain = std::max<int64_t>(0, smax);
+		slack = -o - e + 2;
+		break;
+	}
+	if (pmax > 127 || smin + pconst < -127)
+		return;
+	const int64_t wmax = (int64_t)SA_SYS_CLASSES[SA_SYS_NCLASSES - 1].G * SA_SYS_CLASSES[SA_SYS_NCLASSES - 1].K;
+	if ((gain * wmax + slack) * (SA_SYS_CHUNK + 2) >= ((int64_t)1 << 29))
+		return;
+	ctx->sys_ok = true;
+	ctx->sys_pconst = (int32_t)pconst;
+	ctx->sys_q = (int32_t)q;
+	ctx->sys_gain = gain;
+	ctx->sys_slack = slack;
+}
+
+/* smallest kernel class whose column budget W = G*K holds a column sequence of length n; -1 if none */
+static int systolic_class_for(int32_t n)
+{
+	for (int c = 0; c < SA_SYS_NCLASSES; c++)
+		if (SA_SYS_CLASSES[c].G * SA_SYS_CLASSES[c].K >= n)
+			return c;
+	return -1;
+}
+
 extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa_scoring *sc)
 {
 	if (!sc) {
@@ -164,8 +262,9 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		return nullptr;
 	}
 	std::vector<uint8_t> codes;
+	std::vector<int32_t> off;
 	int32_t max_len = 0;
-	if (!validate_and_encode(in, *sc, codes, max_len))
+	if (!validate_and_encode(in, *sc, codes, off, max_len))
 		return nullptr;
 	if (!device_ready(device))
 		return nullptr;
@@ -176,7 +275,14 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	ctx->max_len = max_len;
 	ctx->pairs = (int64_t)in.num * (in.num - 1) / 2;
 	ctx->sc = *sc;
-	ctx->meta.assign(in.meta, in.meta + in.num);
+	ctx->meta.resize((size_t)in.num);
+	for (int32_t k = 0; k < in.num; k++)
+		ctx->meta[(size_t)k] = sa_meta{ off[(size_t)k], in.meta[k].len };
+	ctx->off = off;
+	systolic_setup(ctx);
+	int8_t sub8[SA_SUB_DIM * SA_SUB_DIM];
+	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++)
+		sub8[k] = (int8_t)std::max(-128, std::min(127, sc->sub[k]));
 
 	bool ok = false;
 	do {
@@ -184,8 +290,12 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		SA_HIP_CHECK(hipMalloc(&ctx->d_meta, sizeof(sa_meta) * (size_t)in.num), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_sub, sizeof(sc->sub)), break);
 		SA_HIP_CHECK(hipMemcpy(ctx->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice), break);
-		SA_HIP_CHECK(hipMemcpy(ctx->d_meta, in.meta, sizeof(sa_meta) * (size_t)in.num, hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(ctx->d_meta, ctx->meta.data(), sizeof(sa_meta) * (size_t)in.num, hipMemcpyHostToDevice), break);
 		SA_HIP_CHECK(hipMemcpy(ctx->d_sub, sc->sub, sizeof(sc->sub), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_off, sizeof(int32_t) * off.size()), break);
+		SA_HIP_CHECK(hipMemcpy(ctx->d_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_sub8, sizeof(sub8)), break);
+		SA_HIP_CHECK(hipMemcpy(ctx->d_sub8, sub8, sizeof(sub8), hipMemcpyHostToDevice), break);
 
 		/* strip-boundary scratch of the pair-per-wave kernels: 2*(max+2) ints per resident wave */
 		hipDeviceProp_t prop;
@@ -212,12 +322,15 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 		return;
 	(void)hipSetDevice(ctx->device);
 	for (auto &ev : ctx->events) {
-		(void)hipEventDestroy(ev.first);
-		(void)hipEventDestroy(ev.second);
+		(void)hipEventDestroy(ev.e0);
+		(void)hipEventDestroy(ev.e1);
 	}
+	plan_release(ctx);
 	(void)hipFree(ctx->d_codes);
 	(void)hipFree(ctx->d_meta);
+	(void)hipFree(ctx->d_off);
 	(void)hipFree(ctx->d_sub);
+	(void)hipFree(ctx->d_sub8);
 	(void)hipFree(ctx->d_scratch);
 	delete ctx;
 }
@@ -308,36 +421,136 @@ extern "C" void sa_ctx_timing(sa_ctx *ctx, int enable)
 		return;
 	(void)hipSetDevice(ctx->device);
 	for (auto &ev : ctx->events) {
-		(void)hipEventDestroy(ev.first);
-		(void)hipEventDestroy(ev.second);
+		(void)hipEventDestroy(ev.e0);
+		(void)hipEventDestroy(ev.e1);
 	}
 	ctx->events.clear();
-	ctx->launches = 0;
 	ctx->timing = enable != 0;
 }
 
-extern "C" int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64_t *launches, double *total_ms)
+extern "C" int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64_t *launches, double *total_ms,
+				  int64_t *pairs, int64_t *cells, double *all_kernels_ms)
 {
 	if (!ctx)
 		return 1;
 	(void)hipSetDevice(ctx->device);
-	double ms = 0.0;
+	struct Acc {
+		double ms = 0;
+		int64_t n = 0, pairs = 0, cells = 0;
+	};
+	std::vector<std::pair<std::string, Acc>> acc;
+	double all = 0.0;
 	for (auto &ev : ctx->events) {
-		SA_HIP_CHECK(hipEventSynchronize(ev.second), return 1);
+		SA_HIP_CHECK(hipEventSynchronize(ev.e1), return 1);
 		float t = 0.f;
-		SA_HIP_CHECK(hipEventElapsedTime(&t, ev.first, ev.second), return 1);
-		ms += t;
+		SA_HIP_CHECK(hipEventElapsedTime(&t, ev.e0, ev.e1), return 1);
+		all += t;
+		auto it = std::find_if(acc.begin(), acc.end(), [&](const auto &p) { return p.first == ev.name; });
+		if (it == acc.end()) {
+			acc.emplace_back(ev.name, Acc());
+			it = acc.end() - 1;
+		}
+		it->second.ms += t;
+		it->second.n++;
+		it->second.pairs += ev.pairs;
+		it->second.cells += ev.cells;
 	}
+	const std::pair<std::string, Acc> *dom = nullptr;
+	for (auto &p : acc)
+		if (!dom || p.second.ms > dom->second.ms)
+			dom = &p;
 	if (kernel_name && cap > 0) {
-		strncpy(kernel_name, ctx->kernel_name.c_str(), (size_t)cap - 1);
+		strncpy(kernel_name, dom ? dom->first.c_str() : "", (size_t)cap - 1);
 		kernel_name[cap - 1] = 0;
 	}
 	if (launches)
-		*launches = ctx->launches;
+		*launches = dom ? dom->second.n : 0;
 	if (total_ms)
-		*total_ms = ms;
+		*total_ms = dom ? dom->second.ms : 0.0;
+	if (pairs)
+		*pairs = dom ? dom->second.pairs : 0;
+	if (cells)
+		*cells = dom ? dom->second.cells : 0;
+	if (all_kernels_ms)
+		*all_kernels_ms = all;
 	return 0;
 }
+
+/* ---- launch planning for a packed range ------------------------------------------------- */
+
+static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
+{
+	if (ctx->plan.start == start && ctx->plan.count == count)
+		return true;
+	plan_release(ctx);
+	const int64_t end = start + count;
+	std::vector<std::vector<int32_t>> jl((size_t)SA_SYS_NCLASSES), tp((size_t)SA_SYS_NCLASSES);
+	std::vector<int64_t> cpairs((size_t)SA_SYS_NCLASSES, 0), ccells((size_t)SA_SYS_NCLASSES, 0);
+	std::vector<int64_t> lenpre((size_t)ctx->num + 1, 0);
+	for (int32_t k = 0; k < ctx->num; k++)
+		lenpre[(size_t)k + 1] = lenpre[(size_t)k] + ctx->meta[(size_t)k].len;
+	sa_ctx::Plan plan;
+	const int32_t j0 = column_of(start), j1 = column_of(end - 1);
+	for (int32_t j = j0; j <= j1; j++) {
+		const int64_t tri = (int64_t)j * (j - 1) / 2;
+		const int64_t ia = std::max<int64_t>(0, start - tri), ib = std::min<int64_t>(j, end - tri);
+		if (ib <= ia)
+			continue;
+		const int32_t n = ctx->meta[(size_t)j].len;
+		const int cls = ctx->sys_ok ? systolic_class_for(n) : -1;
+		if (cls < 0) {
+			if (!plan.generic.empty() && plan.generic.back().first + plan.generic.back().second == tri + ia)
+				plan.generic.back().second += ib - ia;
+			else
+				plan.generic.emplace_back(tri + ia, ib - ia);
+			continue;
+		}
+		const int rows = (64 / SA_SYS_CLASSES[cls].G) * SA_SYS_CHUNK;
+		if (tp[(size_t)cls].empty())
+			tp[(size_t)cls].push_back(0);
+		const int64_t tiles = (ib - ia + rows - 1) / rows;
+		if ((int64_t)tp[(size_t)cls].back() + tiles > INT32_MAX) {
+			sa_set_error("packed range too large for one launch; split it into smaller ranges");
+			return false;
+		}
+		jl[(size_t)cls].push_back(j);
+		tp[(size_t)cls].push_back(tp[(size_t)cls].back() + (int32_t)tiles);
+		cpairs[(size_t)cls] += ib - ia;
+		ccells[(size_t)cls] += (int64_t)n * (lenpre[(size_t)ib] - lenpre[(size_t)ia]);
+	}
+	bool ok = true;
+	for (int cls = 0; cls < SA_SYS_NCLASSES && ok; cls++) {
+		if (jl[(size_t)cls].empty())
+			continue;
+		sa_ctx::ClassLaunch cl;
+		cl.cls = cls;
+		cl.ncols = (int32_t)jl[(size_t)cls].size();
+		cl.ntiles = tp[(size_t)cls].back();
+		cl.pairs = cpairs[(size_t)cls];
+		cl.cells = ccells[(size_t)cls];
+		SA_HIP_CHECK(hipMalloc(&cl.d_jlist, sizeof(int32_t) * jl[(size_t)cls].size()), ok = false);
+		if (ok) {
+			SA_HIP_CHECK(hipMalloc(&cl.d_tprefix, sizeof(int32_t) * tp[(size_t)cls].size()), ok = false);
+		}
+		if (ok) {
+			SA_HIP_CHECK(hipMemcpy(cl.d_jlist, jl[(size_t)cls].data(), sizeof(int32_t) * jl[(size_t)cls].size(),
+					       hipMemcpyHostToDevice), ok = false);
+		}
+		if (ok) {
+			SA_HIP_CHECK(hipMemcpy(cl.d_tprefix, tp[(size_t)cls].data(), sizeof(int32_t) * tp[(size_t)cls].size(),
+					       hipMemcpyHostToDevice), ok = false);
+		}
+		plan.classes.push_back(cl);
+	}
+	plan.start = start;
+	plan.count = count;
+	ctx->plan = plan;
+	if (!ok)
+		plan_release(ctx);
+	return ok;
+}
+
+static const char *const METHOD_TAG[] = { "nw", "ga", "sw" };
 
 extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream)
 {
@@ -350,35 +563,84 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		return 0;
 	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
 	hipStream_t s = (hipStream_t)stream;
+	if (!plan_build(ctx, start, count))
+		return 1;
 
-	SaGenericArgs a{};
-	a.st.codes = ctx->d_codes;
-	a.st.meta = ctx->d_meta;
-	a.st.num = ctx->num;
-	a.sub = ctx->d_sub;
-	a.gap_pen = ctx->sc.gap_pen;
-	a.gap_opn = ctx->sc.gap_opn;
-	a.gap_ext = ctx->sc.gap_ext;
-	a.start = start;
-	a.count = count;
-	a.out = d_scores;
-	a.scratch = ctx->d_scratch;
-	a.scratch_stride = ctx->scratch_stride;
-	const int blocks = (int)std::min<int64_t>(ctx->generic_blocks, (count + 3) / 4);
+	auto timed_begin = [&](hipEvent_t &e0, hipEvent_t &e1) -> bool {
+		if (!ctx->timing)
+			return true;
+		SA_HIP_CHECK(hipEventCreate(&e0), return false);
+		SA_HIP_CHECK(hipEventCreate(&e1), return false);
+		SA_HIP_CHECK(hipEventRecord(e0, s), return false);
+		return true;
+	};
+	auto timed_end = [&](const std::string &name, hipEvent_t e0, hipEvent_t e1, int64_t pairs, int64_t cells) -> bool {
+		if (!ctx->timing)
+			return true;
+		SA_HIP_CHECK(hipEventRecord(e1, s), return false);
+		ctx->events.push_back(sa_ctx::Timed{ name, e0, e1, pairs, cells });
+		return true;
+	};
 
-	hipEvent_t e0 = nullptr, e1 = nullptr;
-	if (ctx->timing) {
-		SA_HIP_CHECK(hipEventCreate(&e0), return 1);
-		SA_HIP_CHECK(hipEventCreate(&e1), return 1);
-		SA_HIP_CHECK(hipEventRecord(e0, s), return 1);
+	/* systolic streaming kernels: one launch per column-length class */
+	for (const auto &cl : ctx->plan.classes) {
+		const int W = SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
+		SaSysArgs a{};
+		a.codes = ctx->d_codes;
+		a.off = ctx->d_off;
+		a.sub8 = ctx->d_sub8;
+		a.jlist = cl.d_jlist;
+		a.tprefix = cl.d_tprefix;
+		a.ncols = cl.ncols;
+		a.num = ctx->num;
+		a.start = start;
+		a.end = start + count;
+		a.out = d_scores;
+		a.pconst = ctx->sys_pconst;
+		a.q = ctx->sys_q;
+		a.gap_g = ctx->sc.gap_pen;
+		a.gap_o = ctx->sc.gap_opn;
+		a.gap_e = ctx->sc.gap_ext;
+		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		if (!timed_begin(e0, e1))
+			return 1;
+		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, cl.ntiles, s), return 1);
+		char name[64];
+		snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
+			 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
+		if (!timed_end(name, e0, e1, cl.pairs, cl.cells))
+			return 1;
 	}
-	SA_HIP_CHECK(sa_launch_generic(ctx->sc.method, a, blocks, s), return 1);
-	if (ctx->timing) {
-		SA_HIP_CHECK(hipEventRecord(e1, s), return 1);
-		ctx->events.emplace_back(e0, e1);
+
+	/* everything the fast path does not cover: pair-per-wave kernels on contiguous packed runs */
+	for (const auto &run : ctx->plan.generic) {
+		SaGenericArgs a{};
+		a.st.codes = ctx->d_codes;
+		a.st.meta = ctx->d_meta;
+		a.st.num = ctx->num;
+		a.sub = ctx->d_sub;
+		a.gap_pen = ctx->sc.gap_pen;
+		a.gap_opn = ctx->sc.gap_opn;
+		a.gap_ext = ctx->sc.gap_ext;
+		a.start = run.first;
+		a.count = run.second;
+		a.out = d_scores + (run.first - start);
+		a.scratch = ctx->d_scratch;
+		a.scratch_stride = ctx->scratch_stride;
+		const int blocks = (int)std::min<int64_t>(ctx->generic_blocks, (run.second + 3) / 4);
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		if (!timed_begin(e0, e1))
+			return 1;
+		SA_HIP_CHECK(sa_launch_generic(ctx->sc.method, a, blocks, s), return 1);
+		int64_t run_cells = 0;
+		if (ctx->timing) {
+			PairPlan pp(ctx->meta.data(), ctx->num);
+			run_cells = pp.cells_before(run.first + run.second) - pp.cells_before(run.first);
+		}
+		if (!timed_end(sa_generic_kernel_name(ctx->sc.method), e0, e1, run.second, run_cells))
+			return 1;
 	}
-	ctx->kernel_name = sa_generic_kernel_name(ctx->sc.method);
-	ctx->launches++;
 	return 0;
 }
 

@@ -42,6 +42,41 @@ struct SaGenericArgs {
 	int64_t scratch_stride;       /* ints per wave = 2*(max_len+2)                          */
 };
 
+/* ---- systolic streaming kernels (sa_systolic.hip) ------------------------ */
+#define SA_SYS_CHUNK 64 /* sequences streamed per lane group and wave-tile */
+/* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K */
+#define SA_SYS_CLASS_LIST(X)                                                                        \
+	X(0, 16, 4) X(1, 16, 5) X(2, 16, 6) X(3, 16, 7) X(4, 16, 8)                                 \
+	X(5, 32, 5) X(6, 32, 6) X(7, 32, 7) X(8, 32, 8)                                             \
+	X(9, 64, 5) X(10, 64, 6) X(11, 64, 7) X(12, 64, 8)                                          \
+	X(13, 64, 10) X(14, 64, 12) X(15, 64, 14) X(16, 64, 16)
+struct SaSysClass {
+	int G, K;
+};
+static const SaSysClass SA_SYS_CLASSES[] = {
+#define SA_SYS_ENTRY(IDX, G_, K_) { G_, K_ },
+	SA_SYS_CLASS_LIST(SA_SYS_ENTRY)
+#undef SA_SYS_ENTRY
+};
+enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLASSES[0])) };
+
+struct SaSysArgs {
+	const uint8_t *codes;    /* encoded store, tight layout: sequence k at off[k], terminator after it */
+	const int32_t *off;      /* num+1 offsets; len_k = off[k+1]-off[k]-1                              */
+	const int8_t *sub8;      /* s8[24*24] substitution matrix                                         */
+	const int32_t *jlist;    /* columns (ascending) handled by this launch                            */
+	const int32_t *tprefix;  /* wave-tiles before jlist[k]; ncols+1 entries                           */
+	int32_t ncols, num;
+	int64_t start, end;      /* packed pair range [start, end) being computed                         */
+	int32_t *out;            /* out[p - start]                                                        */
+	int32_t pconst;          /* constant folded into the profile: NW -2g, GA -e-o, SW -o              */
+	int32_t q;               /* GA: o - e (<= 0); else 0                                              */
+	int32_t gap_g, gap_o, gap_e;
+	int32_t delta;           /* baseline raise per sequence                                           */
+};
+
+hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles, hipStream_t s);
+
 /* ---- launchers implemented in the .hip files ---------------------------- */
 hipError_t sa_launch_generic(int method, const SaGenericArgs &a, int blocks, hipStream_t s);
 const char *sa_generic_kernel_name(int method);
