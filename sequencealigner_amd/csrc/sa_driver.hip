@@ -602,13 +602,34 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.gap_o = ctx->sc.gap_opn;
 		a.gap_e = ctx->sc.gap_ext;
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
+		char name[64];
+		snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
+			 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
+		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
+		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
+		unsigned long long *d_stamps = nullptr;
+		if (getenv("SA_HIP_STAMPS")) {
+			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
+			a.stamps = d_stamps;
+		}
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
 		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, cl.ntiles, s), return 1);
-		char name[64];
-		snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
-			 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
+		if (d_stamps) {
+			std::vector<unsigned long long> h(3 * (size_t)cl.ntiles);
+			SA_HIP_CHECK(hipStreamSynchronize(s), return 1);
+			SA_HIP_CHECK(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost), return 1);
+			(void)hipFree(d_stamps);
+			double cyc = 0, rt = 0, steps = 0;
+			for (int32_t k = 0; k < cl.ntiles; k++) {
+				cyc += (double)h[3 * (size_t)k];
+				rt += (double)h[3 * (size_t)k + 1];
+				steps += (double)h[3 * (size_t)k + 2];
+			}
+			fprintf(stderr, "[stamps] %s: %d wave-tiles, %.1f cycles/step per wave, clock %.0f MHz, %.0f steps/tile\n",
+				name, cl.ntiles, cyc / steps, cyc / rt * 100.0, steps / cl.ntiles);
+		}
 		if (!timed_end(name, e0, e1, cl.pairs, cl.cells))
 			return 1;
 	}

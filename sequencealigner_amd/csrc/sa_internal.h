@@ -44,6 +44,9 @@ struct SaGenericArgs {
 
 /* ---- systolic streaming kernels (sa_systolic.hip) ------------------------ */
 #define SA_SYS_CHUNK 64 /* sequences streamed per lane group and wave-tile */
+#ifndef SA_SYS_WPB
+#define SA_SYS_WPB 1    /* waves per workgroup (one wave-tile each)            */
+#endif
 /* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K */
 #define SA_SYS_CLASS_LIST(X)                                                                        \
 	X(0, 16, 4) X(1, 16, 5) X(2, 16, 6) X(3, 16, 7) X(4, 16, 8)                                 \
@@ -73,6 +76,8 @@ struct SaSysArgs {
 	int32_t q;               /* GA: o - e (<= 0); else 0                                              */
 	int32_t gap_g, gap_o, gap_e;
 	int32_t delta;           /* baseline raise per sequence                                           */
+	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
+	                             * steps} of the main loop; nullptr in production                        */
 };
 
 hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles, hipStream_t s);

@@ -25,6 +25,14 @@
  *                    q = o - e <= 0         N = M' + q; X'next = max(N, X')                          5 ops/cell
  *   SW  sw.c:39-57   No = M + o             Y = max(No_up, Yup+e); M = max(max3(No_diag + (S-o), X, Y), B)
  *                                           No = M + o; Xnext = max(No, X+e); best = max(best, M)    9 ops/cell
+ * Row tokens do not travel through registers.  Each lane group keeps the recent part of its stream
+ * in a small LDS ring as pre-shifted profile-row addresses; every 16 steps a lane fetches the 16
+ * tokens it will meet (stream positions t-l ... t-l+15) with immediate-offset ds_reads, so the
+ * systolic "shift" of the row is pure addressing.  Terminators only matter to the group's first lane
+ * (inject the next baseline) and last lane (a score leaves the pipeline): a ballot taken when a block
+ * of tokens is written to the ring gives a wave-uniform 16-bit event mask per block, tested with a
+ * scalar branch per step -- the common step executes no exec-masked code at all.
+ *
  * The per-residue scores (S + constant) of the lane's K columns are a query profile of s8 values in
  * LDS: row = residue code, one private 4/8/16-byte slot per lane of a 32-lane half, so the
  * ds_read is conflict-free by construction; bytes are consumed by SDWA adds (no unpack op).
@@ -50,9 +58,18 @@ __device__ __forceinline__ int dpp_wave_shr1(int old, int src)
 {
 	return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
 }
-__device__ __forceinline__ int dpp_row_shl1(int v)
+
+/* lane i of a DPP row receives v of lane i+n of the same row (n is a constant after unrolling) */
+__device__ __forceinline__ int dpp_row_shl(int v, int n)
 {
-	return __builtin_amdgcn_update_dpp(v, v, 0x101, 0xf, 0xf, false);
+	switch (n) {
+#define SA_SHL(N) case N: return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xf, 0xf, false);
+		SA_SHL(1) SA_SHL(2) SA_SHL(3) SA_SHL(4) SA_SHL(5) SA_SHL(6) SA_SHL(7) SA_SHL(8)
+		SA_SHL(9) SA_SHL(10) SA_SHL(11) SA_SHL(12) SA_SHL(13) SA_SHL(14) SA_SHL(15)
+#undef SA_SHL
+	default:
+		return v;
+	}
 }
 
 /* value of lane-1 inside the group; the group's lane 0 receives `lead` instead */
@@ -83,28 +100,57 @@ __device__ __forceinline__ int slot_byte(const uint4 &w, int q)
 }
 
 template <int METHOD, int G, int K>
-__global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
+__global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
 {
+	constexpr int WPB = SA_SYS_WPB; /* waves per workgroup, each wave owns one wave-tile and its own LDS */
 	constexpr int NG = 64 / G;
 	constexpr int W = G * K;
 	constexpr int RB = K <= 4 ? 4 : K <= 8 ? 8 : 16;  /* bytes per profile slot                    */
-	constexpr int NT = G == 64 ? 2 : 1;               /* one table per 32 distinct column holders  */
-	constexpr int ROWSTRIDE = 32 * RB;
-	constexpr int SH = RB == 4 ? 7 : RB == 8 ? 8 : 9;
+	/* Profile table: row = residue code, one slot per DISTINCT column holder.  G = 16: the 16 lanes of
+	 * a row (lanes l and l+16 of a ds_read lane group share a slot: same address when their residues
+	 * agree, otherwise at worst a 2-way bank conflict -- LDS has ample slack, and the smaller table is
+	 * what lets 8 waves/SIMD fit).  G = 32: 32 slots.  G = 64: two 32-slot tables. */
+	constexpr int NSLOT = G == 16 ? 16 : 32;
+	constexpr int NT = G == 64 ? 2 : 1;
+	constexpr int ROWSTRIDE = NSLOT * RB;
+	constexpr int SH = (RB == 4 ? 2 : RB == 8 ? 3 : 4) + (NSLOT == 16 ? 4 : 5);
 	using slot_t = typename Slot<RB>::type;
 
 	constexpr int TBLSTRIDE = 32 * ROWSTRIDE;        /* power of two: address = tok<<SH | slot_off */
-	__shared__ __attribute__((aligned(16))) uint8_t s_prof[NT == 2 ? 2 * TBLSTRIDE : SA_CODE_ROWS * ROWSTRIDE];
-	__shared__ int32_t s_out[NG * CH];
-	__shared__ int8_t s_sub[SA_SUB_DIM * SA_SUB_DIM];
+	constexpr int PROF_BYTES = NT == 2 ? 2 * TBLSTRIDE : SA_CODE_ROWS * ROWSTRIDE;
+	__shared__ __attribute__((aligned(16))) uint8_t s_prof_all[WPB * PROF_BYTES];
+	/* s_out (scores leaving the pipeline) is only written after the profile build, which is the only
+	 * reader of the staged substitution matrix: they share storage */
+	constexpr int OUT_INTS = NG * CH * 4 > SA_SUB_DIM * SA_SUB_DIM ? NG * CH : SA_SUB_DIM * SA_SUB_DIM / 4;
+	__shared__ int32_t s_out_all[WPB * OUT_INTS];
+	/* token ring per lane group: RING stream positions as u16.  Stored twice (index i and i+RING) so a
+	 * run of 16 consecutive positions never wraps, and in two copies skewed by one position so that
+	 * every lane's run starts on a 4-byte boundary (odd lanes read copy 1): the run is fetched with 8
+	 * aligned ds_read_b32.  (Unaligned wide LDS reads serialize: SQ_LDS_UNALIGNED_STALL.) */
+	constexpr int RING = G == 16 ? 64 : 128;
+	/* bank placement (u16 units; 2 u16 = one 4-byte bank): in one ds_read_b32 lane group (32 lanes) the
+	 * even lanes read 8 (G=16: per row) or 16 consecutive dwords of copy 0 and the odd lanes the same
+	 * dwords of copy 1, and with G=16 two rows = two groups are in flight: copy 1 is displaced by 8/16
+	 * banks and the next group by 16 banks, so the 32 lanes always hit 32 distinct banks. */
+	constexpr int COPY1 = 2 * RING + (G == 16 ? 16 : 32);
+	constexpr int GSTRIDE = G == 16 ? 288 : COPY1 + 2 * RING;
+	__shared__ __attribute__((aligned(16))) uint16_t s_ring_all[WPB * NG * GSTRIDE];
 
-	const int lane = threadIdx.x;
+	const int lane = threadIdx.x & 63;
+	const int wv = threadIdx.x >> 6;
+	uint8_t *s_prof = s_prof_all + wv * PROF_BYTES;
+	int32_t *s_out = s_out_all + wv * OUT_INTS;
+	int8_t *s_sub = reinterpret_cast<int8_t *>(s_out);
+	uint16_t *s_ring = s_ring_all + wv * (NG * GSTRIDE);
 	const int lig = lane & (G - 1);
 	const int grp = lane / G;
 	const bool leader = lig == 0;
 
 	/* ---- which wave-tile: (column j, block of NG*CH rows) ---- */
-	const int32_t t = blockIdx.x;
+	const int32_t ntiles = A.tprefix[A.ncols];
+	const int32_t t_raw = (int32_t)blockIdx.x * WPB + wv;
+	const bool active = t_raw < ntiles;          /* surplus waves of the last workgroup recompute */
+	const int32_t t = active ? t_raw : ntiles - 1; /* the last tile and store nothing              */
 	int32_t lo = 0, hi = A.ncols; /* largest k with tprefix[k] <= t */
 	while (hi - lo > 1) {
 		const int32_t mid = (lo + hi) >> 1;
@@ -135,9 +181,12 @@ __global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
 			const int c0 = lig * K + q - (W - n);
 			bq[q] = c0 >= 0 ? (int)A.codes[offj + c0] : -1;
 		}
-		const int slot = lane & 31;
-		const int a_lo = NT == 2 ? 0 : (lane >> 5) * (SA_CODE_ROWS / 2);
-		const int a_hi = NT == 2 ? SA_CODE_ROWS : a_lo + SA_CODE_ROWS / 2;
+		/* lanes holding the same columns split the table rows between them */
+		constexpr int SHARE = NT == 2 ? 1 : 64 / NSLOT;          /* builders per slot: 4, 2 or 1 */
+		constexpr int ROWS_EACH = (SA_CODE_ROWS + SHARE - 1) / SHARE;
+		const int slot = lane & (NSLOT - 1);
+		const int a_lo = NT == 2 ? 0 : (lane / NSLOT) * ROWS_EACH;
+		const int a_hi = NT == 2 ? SA_CODE_ROWS : (a_lo + ROWS_EACH < SA_CODE_ROWS ? a_lo + ROWS_EACH : SA_CODE_ROWS);
 		uint8_t *tbl = s_prof + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0);
 		for (int a = a_lo; a < a_hi; a++) {
 			uint32_t w[RB / 4];
@@ -182,12 +231,45 @@ __global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
 	const int32_t steps = smax + G - 1;
 	const int32_t nblk = (steps + 15) >> 4;
 	const uint8_t *stream = A.codes + sbeg;
+	/* token prefetch: 16 stream bytes per DPP row and block, fetched two blocks ahead of their use.
+	 * The load is unconditional (clamped address); the out-of-stream select happens when the block is
+	 * converted, so the vmcnt wait lands a full block after the issue. */
+	const int32_t last = slen > 0 ? slen - 1 : 0;
+	const int r16 = lane & 15;
 	auto load_block = [&](int32_t blk) -> int {
-		const int32_t pos = (blk << 4) + (lane & 15);
-		return pos < slen ? (int)stream[pos] : (int)SA_CODE_NOP;
+		const int32_t pos = (blk << 4) + r16;
+		return (int)stream[pos < last ? pos : last];
+	};
+	constexpr uint32_t SEPWORD = (uint32_t)SA_CODE_SEP << SH;
+	constexpr uint32_t NOPWORD = (uint32_t)SA_CODE_NOP << SH;
+	auto block_word = [&](int32_t blk, int raw) -> uint32_t { /* token -> profile row address */
+		const int32_t pos = (blk << 4) + r16;
+		return pos < slen ? (uint32_t)raw << SH : NOPWORD;
+	};
+	/* every DPP row writes the ring of the group it belongs to; only the group's first row carries
+	 * the stream (rows 1.. of a 32/64-lane group write a private scratch half that is never read) */
+	uint16_t *ring = s_ring + grp * GSTRIDE; /* copy 0 at [0, 2*RING), copy 1 at [COPY1, COPY1 + 2*RING) */
+	const bool feeder = (lane & (G - 1)) < 16;
+	auto ring_write = [&](int32_t blk, uint32_t word) {
+		if (feeder) {
+			const int p = (blk << 4) + r16;
+			const int i0 = p & (RING - 1), i1 = (p + 1) & (RING - 1);
+			ring[i0] = (uint16_t)word;
+			ring[i0 + RING] = (uint16_t)word;
+			ring[COPY1 + i1] = (uint16_t)word;
+			ring[COPY1 + i1 + RING] = (uint16_t)word;
+		}
+	};
+	/* terminator positions of a block of tokens: wave ballot (bit = lane) */
+	auto sep_ballot = [&](uint32_t word) -> unsigned long long { return __ballot(feeder && word == SEPWORD); };
+	/* any group: wave-uniform 16-bit mask of the block's terminator positions */
+	auto fold16 = [&](unsigned long long m) -> uint32_t {
+		m |= m >> 32;
+		m |= m >> 16;
+		return (uint32_t)m & 0xffffu;
 	};
 
-	const uint32_t slot_off = (uint32_t)((lane & 31) * RB + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0));
+	const uint32_t slot_off = (uint32_t)((lane & (NSLOT - 1)) * RB + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0));
 	const int32_t delta = A.delta;
 	const int32_t gq = A.q, go = A.gap_o, ge = A.gap_e;
 
@@ -196,61 +278,124 @@ __global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
 	int Y[K];        /* GA: Y'   SW: Y                                          */
 	int vprev;       /* value of the column left of V[0], previous row (diag)   */
 	int xout;        /* GA/SW: X of the column right of V[K-1], current row     */
-	int injn;        /* boundary value injected at lane 0 on an ordinary row    */
-	int floorB = 0;  /* SW: current baseline = zero floor of the local alignment */
+	int fl = 0;      /* SW: floor of the row this lane is processing (travels with the row) */
 	int best = 0, carry = NEG;
 	int nsep = 0;
+	/* boundary value the group's first lane injects on an ordinary row of the FIRST sequence:
+	 * NW  B,  GA  B + 2q,  SW  B + o  (B = 0); a terminator row injects cspecial more (GA: B' + q) */
+	const int inj0 = METHOD == SA_METHOD_NW ? 0 : METHOD == SA_METHOD_GA ? 2 * gq : go;
+	const int cspecial = METHOD == SA_METHOD_GA ? -gq : 0;
 	if (METHOD == SA_METHOD_NW) {
-		injn = 0;
 		vprev = 0;
 		xout = 0;
 #pragma unroll
 		for (int q = 0; q < K; q++)
 			V[q] = 0, Y[q] = 0;
 	} else if (METHOD == SA_METHOD_GA) {
-		injn = 2 * gq;
 		vprev = leader ? gq : 2 * gq;
 		xout = gq;
 #pragma unroll
 		for (int q = 0; q < K; q++)
 			V[q] = 2 * gq, Y[q] = 2 * gq;
 	} else {
-		injn = go;
 		vprev = go;
 		xout = go;
 #pragma unroll
 		for (int q = 0; q < K; q++)
 			V[q] = go, Y[q] = go;
 	}
-	const int cspecial = METHOD == SA_METHOD_GA ? -gq : 0;
 
-	int tok = SA_CODE_NOP;
-	int tokq = load_block(0);
+	/* Injection vector of a block: feeder lane k holds the boundary value of the row at stream
+	 * position 16*blk + k, i.e. inj0 + DELTA * (terminators at positions <= that one) (+ cspecial on
+	 * the terminator row itself).  The group's first lane picks entry s at step s with a constant
+	 * row_shl:s DPP, so baseline raises need no branch and no per-step state. */
+	int seps_before = 0; /* terminators of this lane's row-stream in earlier blocks */
+	auto inject_vector = [&](unsigned long long m, uint32_t word) -> int {
+		const uint32_t half = (lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+		const uint32_t seg = (lane & 16) ? half >> 16 : half & 0xffffu;
+		const int incl = __builtin_popcount(seg & ((2u << r16) - 1u));
+		const int v = inj0 + delta * (seps_before + incl) + (word == SEPWORD ? cspecial : 0);
+		seps_before += __builtin_popcount(seg);
+		return v;
+	};
+
+	/* the 16 tokens a lane meets in block blk: stream positions 16*blk - lig + s, two per dword */
+	auto ring_run = [&](int32_t blk, uint32_t (&two)[8]) {
+		const int phase = lig & 1;
+		const uint32_t *rp = reinterpret_cast<const uint32_t *>(
+			ring + phase * COPY1 + (((blk << 4) - lig + phase) & (RING - 1)));
+#pragma unroll
+		for (int k = 0; k < 8; k++)
+			two[k] = rp[k];
+	};
+	auto tok_of = [&](const uint32_t (&two)[8], int s) -> uint32_t {
+		return (s & 1) ? two[s >> 1] >> 16 : two[s >> 1] & 0xffffu;
+	};
+	auto prof_row = [&](uint32_t word) -> slot_t {
+		return *reinterpret_cast<const slot_t *>(s_prof + (word | slot_off));
+	};
+
+	/* ---- prologue: empty ring, block 0 in the ring, block 1 in flight ---- */
+	for (int k = lane; k < NG * GSTRIDE; k += 64)
+		s_ring[k] = (uint16_t)NOPWORD;
+	__syncthreads();
+	/* terminator bits seen by the LAST lane of a group: position p reaches it G-1 steps late.
+	 * hi bit k = position t0+k (current block), lo bit 64-d = position t0-d */
+	unsigned long long ev_lo = 0, ev_hi;
+	int injvec;
+	{
+		const uint32_t w0 = block_word(0, load_block(0));
+		ring_write(0, w0);
+		const unsigned long long m0 = sep_ballot(w0);
+		ev_hi = fold16(m0);
+		injvec = inject_vector(m0, w0);
+	}
+	int raw_next = load_block(1);
+	__syncthreads();
+	uint32_t w2[8]; /* current block's tokens */
+	ring_run(0, w2);
+	constexpr int PD = 4; /* profile rows are requested PD steps ahead of their use */
+	slot_t pq[PD];
+#pragma unroll
+	for (int s = 0; s < PD; s++)
+		pq[s] = prof_row(tok_of(w2, s));
+
+	unsigned long long st_c = 0, st_r = 0;
+	if (A.stamps) {
+		st_c = __builtin_amdgcn_s_memtime();
+		st_r = __builtin_amdgcn_s_memrealtime();
+	}
 	for (int32_t blk = 0; blk < nblk; blk++) {
-		const int tokn = load_block(blk + 1);
+		/* steps of this block at which the last lane of some group meets a terminator */
+		const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1))) & 0xffffu);
+		/* next block's tokens go into the ring while this block computes */
+		const uint32_t wn = block_word(blk + 1, raw_next);
+		ring_write(blk + 1, wn);
+		const unsigned long long mn = sep_ballot(wn);
+		const int injvec_next = inject_vector(mn, wn);
+		raw_next = load_block(blk + 2);
+		uint32_t w2n[8]; /* next block's tokens, fetched mid-block so no LDS latency is exposed at the seam */
+
 #pragma unroll
 		for (int s = 0; s < 16; s++) {
-			tok = shift_in<G>(tokq, tok, leader);
-			tokq = dpp_row_shl1(tokq);
-			const slot_t pw = *reinterpret_cast<const slot_t *>(s_prof + (((uint32_t)tok << SH) | slot_off));
-			int cin = 0;
-			if (METHOD == SA_METHOD_SW)
-				cin = shift_in<G>(NEG, carry, leader);
-			int inj = injn;
-			if (tok >= SA_CODE_SEP) {
-				if (tok == SA_CODE_SEP) {
-					int res = V[K - 1];
-					if (METHOD == SA_METHOD_SW) {
-						carry = imax(cin, best);
-						res = carry;
-						floorB += delta;
-					}
-					if (lig == G - 1)
-						s_out[grp * CH + nsep] = res;
+			const slot_t pw = pq[s % PD];
+			if (s == 6)
+				ring_run(blk + 1, w2n);
+			pq[s % PD] = prof_row(s + PD < 16 ? tok_of(w2, s + PD) : tok_of(w2n, s + PD - 16));
+			/* boundary value of this row for the group's first lane */
+			const int inj = dpp_row_shl(injvec, s);
+			if (METHOD == SA_METHOD_SW) {
+				carry = imax(shift_in<G>(NEG, carry, leader), best);
+			}
+			if (__builtin_expect((ev >> s) & 1u, 0)) { /* wave-uniform, rare: a score leaves the pipeline */
+				/* the empty volatile statement keeps this a scalar branch (s_bitcmp + s_cbranch_scc):
+				 * without it the uniform test is folded into the per-lane one and every step pays
+				 * v_cmp + s_and_saveexec + s_cbranch_execz (measured: +200 cycles per step and wave) */
+				asm volatile("" ::: "memory");
+				if (lig == G - 1 && tok_of(w2, s) == SEPWORD) {
+					s_out[grp * CH + nsep] = METHOD == SA_METHOD_SW ? carry : V[K - 1];
 					nsep++;
-					injn += delta;
 				}
-				inj = injn + cspecial;
 			}
 			const int vleft = shift_in<G>(inj, V[K - 1], leader);
 			int d[K];
@@ -276,10 +421,11 @@ __global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
 				xout = x;
 			} else {
 				int x = shift_in<G>(inj, xout, leader);
+				fl = shift_in<G>(inj - go, fl, leader); /* floor = baseline of the row's sequence */
 #pragma unroll
 				for (int q = 0; q < K; q++) {
 					const int y = imax(V[q], Y[q] + ge);
-					const int m = imax(imax3(d[q], x, y), floorB);
+					const int m = imax(imax3(d[q], x, y), fl);
 					Y[q] = y;
 					V[q] = m + go;
 					x = imax(V[q], x + ge);
@@ -289,7 +435,17 @@ __global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
 			}
 			vprev = vleft;
 		}
-		tokq = tokn;
+#pragma unroll
+		for (int k = 0; k < 8; k++)
+			w2[k] = w2n[k];
+		injvec = injvec_next;
+		ev_lo = (ev_lo >> 16) | (ev_hi << 48);
+		ev_hi = fold16(mn);
+	}
+	if (A.stamps && lane == 0) {
+		A.stamps[3 * (size_t)t + 0] = __builtin_amdgcn_s_memtime() - st_c;
+		A.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
+		A.stamps[3 * (size_t)t + 2] = (unsigned long long)nblk * 16;
 	}
 	__syncthreads();
 
@@ -298,7 +454,7 @@ __global__ __launch_bounds__(64) void sa_k_systolic(SaSysArgs A)
 	for (int g = 0; g < NG; g++) {
 		int32_t c = i_count - g * CH;
 		c = c < 0 ? 0 : c > CH ? CH : c;
-		if (lane < c) {
+		if (lane < c && active) {
 			const int32_t i = i_begin + g * CH + lane;
 			const int32_t m = A.off[i + 1] - A.off[i] - 1;
 			const int32_t raw = s_out[g * CH + lane] - lane * delta;
@@ -318,7 +474,8 @@ template <int METHOD> hipError_t launch_method(int cls, const SaSysArgs &a, int 
 {
 #define SA_CASE(IDX, G_, K_)                                                                              \
 	case IDX:                                                                                         \
-		hipLaunchKernelGGL((sa_k_systolic<METHOD, G_, K_>), dim3(tiles), dim3(64), 0, s, a);     \
+		hipLaunchKernelGGL((sa_k_systolic<METHOD, G_, K_>), dim3((tiles + SA_SYS_WPB - 1) / SA_SYS_WPB),  \
+				   dim3(64 * SA_SYS_WPB), 0, s, a);                                        \
 		break;
 	switch (cls) {
 		SA_SYS_CLASS_LIST(SA_CASE)

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): bench + rocprofv3 kernel-trace stats + PMC passes.
+# Usage: tools/profile_gpu.sh <tag> [bench args...]
+set -o pipefail
+TAG=${1:-r01}; shift
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline $@"
+python3 bench.py --steps 3 --warmup 1 "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
+cat $OUT/bench.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ROOT/bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err || { tail -5 $OUT/pmc_fetch.err; exit 1; }
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_write.err || { tail -5 $OUT/pmc_write.err; exit 1; }
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc_sq.err || { tail -5 $OUT/pmc_sq.err; exit 1; }
+cd $ROOT
+python3 tools/summarize_profile.py $OUT > $OUT/summary.txt
+cat $OUT/summary.txt

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile_gpu.sh output directory into the summary that is committed under profiles/."""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+print(f"# profile summary of {os.path.basename(d)}")
+for name in ("bench.json",):
+    p = os.path.join(d, name)
+    if os.path.exists(p):
+        line = open(p).read().strip().splitlines()[-1]
+        j = json.loads(line)
+        print("bench:", json.dumps({k: j[k] for k in ("value", "ms_per_step", "gcups", "roofline") if k in j}))
+
+# kernel stats
+for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursive=True):
+    print("\n## rocprofv3 --kernel-trace --stats :", os.path.relpath(f, d))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("  {Name:60s} calls={Calls:>5s} total_ns={TotalDurationNs:>14s} avg_ns={AverageNs:>14s} pct={Percentage}".format(**r))
+
+# per-dispatch counters, aggregated per kernel
+def agg(sub, counters):
+    acc = defaultdict(lambda: defaultdict(float))
+    cnt = defaultdict(int)
+    for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"][:70]
+            acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r["Counter_Name"] == counters[0]:
+                cnt[k] += 1
+    return acc, cnt
+
+for sub, counters in (("pmc_fetch", ["FETCH_SIZE"]), ("pmc_write", ["WRITE_SIZE"]),
+                      ("pmc_sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES",
+                                  "SQ_BUSY_CYCLES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"])):
+    acc, cnt = agg(sub, counters)
+    if not acc:
+        continue
+    print(f"\n## rocprofv3 --pmc {' '.join(counters)}  (sum over dispatches; n = dispatches)")
+    for k in sorted(acc, key=lambda k: -sum(acc[k].values()))[:10]:
+        vals = "  ".join(f"{c}={acc[k].get(c, 0):.4g}" for c in counters)
+        print(f"  {k:70s} n={cnt[k]:<4d} {vals}")
