@@ -34,6 +34,8 @@ struct sa_ctx {
 	int32_t *d_scratch = nullptr;
 	int64_t scratch_stride = 0;
 	int generic_blocks = 0;
+	unsigned *d_counters = nullptr; /* one tile counter per systolic class launch */
+	int persistent_wgs = 0;         /* workgroups of a persistent systolic launch  */
 	/* systolic fast path: parameters and validity (see systolic_setup) */
 	bool sys_ok = false;
 	int32_t sys_pconst = 0, sys_q = 0;
@@ -307,6 +309,8 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		blocks = std::max<int64_t>(prop.multiProcessorCount, std::min(blocks, budget / per_block));
 		ctx->generic_blocks = (int)blocks;
 		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * SA_SYS_NCLASSES), break);
+		ctx->persistent_wgs = prop.multiProcessorCount * 32;
 		ok = true;
 	} while (0);
 	if (!ok) {
@@ -332,6 +336,7 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 	(void)hipFree(ctx->d_sub);
 	(void)hipFree(ctx->d_sub8);
 	(void)hipFree(ctx->d_scratch);
+	(void)hipFree(ctx->d_counters);
 	delete ctx;
 }
 
@@ -582,7 +587,10 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		return true;
 	};
 
-	/* systolic streaming kernels: one launch per column-length class */
+	/* systolic streaming kernels: one persistent launch per column-length class */
+	if (!ctx->plan.classes.empty()) {
+		SA_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * SA_SYS_NCLASSES, s), return 1);
+	}
 	for (const auto &cl : ctx->plan.classes) {
 		const int W = SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
 		SaSysArgs a{};
@@ -602,6 +610,7 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.gap_o = ctx->sc.gap_opn;
 		a.gap_e = ctx->sc.gap_ext;
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
+		a.counter = ctx->d_counters + cl.cls;
 		char name[64];
 		snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
 			 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
@@ -615,7 +624,8 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
-		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, cl.ntiles, s), return 1);
+		const int wgs = (int)std::min<int64_t>(ctx->persistent_wgs, (cl.ntiles + SA_SYS_WPB - 1) / SA_SYS_WPB);
+		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
 		if (d_stamps) {
 			std::vector<unsigned long long> h(3 * (size_t)cl.ntiles);
 			SA_HIP_CHECK(hipStreamSynchronize(s), return 1);

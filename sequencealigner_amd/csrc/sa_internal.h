@@ -76,11 +76,13 @@ struct SaSysArgs {
 	int32_t q;               /* GA: o - e (<= 0); else 0                                              */
 	int32_t gap_g, gap_o, gap_e;
 	int32_t delta;           /* baseline raise per sequence                                           */
+	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
 };
 
-hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles, hipStream_t s);
+/* `workgroups` persistent workgroups pull the launch's wave-tiles from a.counter */
+hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workgroups, hipStream_t s);
 
 /* ---- launchers implemented in the .hip files ---------------------------- */
 hipError_t sa_launch_generic(int method, const SaGenericArgs &a, int blocks, hipStream_t s);

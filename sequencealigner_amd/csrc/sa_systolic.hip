@@ -99,8 +99,9 @@ __device__ __forceinline__ int slot_byte(const uint4 &w, int q)
 	return (int)(int8_t)(v >> (8 * (q & 3)));
 }
 
+/* one wave-tile: column j = A.jlist[..] against 64/G streams of up to 64 row sequences */
 template <int METHOD, int G, int K>
-__global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
+__device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t t_raw, const int32_t ntiles)
 {
 	constexpr int WPB = SA_SYS_WPB; /* waves per workgroup, each wave owns one wave-tile and its own LDS */
 	constexpr int NG = 64 / G;
@@ -147,8 +148,6 @@ __global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
 	const bool leader = lig == 0;
 
 	/* ---- which wave-tile: (column j, block of NG*CH rows) ---- */
-	const int32_t ntiles = A.tprefix[A.ncols];
-	const int32_t t_raw = (int32_t)blockIdx.x * WPB + wv;
 	const bool active = t_raw < ntiles;          /* surplus waves of the last workgroup recompute */
 	const int32_t t = active ? t_raw : ntiles - 1; /* the last tile and store nothing              */
 	int32_t lo = 0, hi = A.ncols; /* largest k with tprefix[k] <= t */
@@ -470,12 +469,31 @@ __global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
 	}
 }
 
+/* Persistent launch: every wave pulls wave-tiles from a device counter until the class is done, so a
+ * finished tile is followed by the next one without a workgroup relaunch and the launch drains with at
+ * most one tile of imbalance.  (Plain one-tile-per-workgroup grids left ~19 % of the wave slots idle.) */
+template <int METHOD, int G, int K>
+__global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
+{
+	__shared__ int32_t s_next;
+	const int32_t ntiles = A.tprefix[A.ncols];
+	for (;;) {
+		if (threadIdx.x == 0)
+			s_next = (int32_t)atomicAdd(A.counter, (unsigned)SA_SYS_WPB);
+		__syncthreads();
+		const int32_t base = s_next;
+		__syncthreads();
+		if (base >= ntiles)
+			break;
+		systolic_tile<METHOD, G, K>(A, base + (int32_t)(threadIdx.x >> 6), ntiles);
+	}
+}
+
 template <int METHOD> hipError_t launch_method(int cls, const SaSysArgs &a, int tiles, hipStream_t s)
 {
 #define SA_CASE(IDX, G_, K_)                                                                              \
 	case IDX:                                                                                         \
-		hipLaunchKernelGGL((sa_k_systolic<METHOD, G_, K_>), dim3((tiles + SA_SYS_WPB - 1) / SA_SYS_WPB),  \
-				   dim3(64 * SA_SYS_WPB), 0, s, a);                                        \
+		hipLaunchKernelGGL((sa_k_systolic<METHOD, G_, K_>), dim3(tiles), dim3(64 * SA_SYS_WPB), 0, s, a);  \
 		break;
 	switch (cls) {
 		SA_SYS_CLASS_LIST(SA_CASE)
