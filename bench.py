@@ -175,6 +175,13 @@ def main():
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kernel_gcups = k_cells / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         kname = tm["kernel"]
+        # HBM traffic of that kernel per launch from the committed PMC passes (profiles/*_traffic.json), if the
+        # workload and kernel match; null otherwise (it cannot be measured inside this process)
+        traffic = None
+        for tf in sorted((ROOT / "profiles").glob("*_traffic.json")):
+            tj = json.loads(tf.read_text())
+            if tj.get("kernel") == kname and tj.get("workload") == args.config and world == 1 and args.n is None:
+                traffic = tj["traffic_bytes_per_launch"]
         out = {
             "metric": "pair-alignments/sec", "value": value, "unit": "pair-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -185,7 +192,7 @@ def main():
                        "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (" + RCCL all-gather" if world > 1 else "")},
             "gcups": cells * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                          "kernel_avg_ms": avg_ms, "launches": tm["launches"], "algorithmic_bytes_per_launch": alg_bytes,
                          "pairs_per_launch": k_pairs, "all_kernels_ms_per_step": tm["all_kernels_ms"] / args.steps},
             "valu": {"kernel_gcups": kernel_gcups, "reference_ops_per_cell": OPS_PER_CELL[scoring.method_name],
