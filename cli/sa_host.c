@@ -1,0 +1,539 @@
+/* cli/sa_host.c -- see sa_host.h.  Plain C11 + OpenMP + libhdf5. */
+#define _GNU_SOURCE
+#include "sa_host.h"
+
+#include <ctype.h>
+#include <errno.h>
+#include <limits.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <sys/mman.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include <hdf5.h>
+
+static _Thread_local char g_err[512];
+
+static int fail(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return 1;
+}
+
+const char *sa_host_error(void) { return g_err; }
+
+/* ---- length limit: reference src/io/input.c:15-19, src/bio/align.h:23 -------------------- */
+static bool length_ok(int64_t len, int32_t gap_stored)
+{
+	const int64_t seq_len_max = (INT32_MAX - 1) / 2;
+	const int64_t gap = -(int64_t)gap_stored;
+	return gap ? len <= seq_len_max / gap : len <= seq_len_max;
+}
+
+struct builder {
+	uint8_t *w;       /* write cursor (compacts in place over the file image) */
+	uint8_t *base;
+	int32_t num, max;
+	int64_t sum;
+};
+
+/* appends one residue-validated sequence taken from [p, p+n) skipping CR/LF/space(/quote) */
+static int add_sequence(struct builder *b, const uint8_t *p, size_t n, bool skip_quote, const int32_t *lut,
+			int32_t gap, int32_t index1)
+{
+	int32_t slen = 0;
+	uint8_t *start = b->w;
+	for (size_t k = 0; k < n; k++) {
+		const unsigned c = (unsigned)toupper(p[k]);
+		if (c == '\r' || c == '\n' || c == ' ' || (skip_quote && c == '"'))
+			continue;
+		if (c == 0 || c > SCHAR_MAX)
+			return fail("Sequence #%d is corrupted", index1);
+		if (lut[c] < 0)
+			return fail("Sequence #%d is invalid", index1);
+		*b->w++ = (uint8_t)c;
+		slen++;
+	}
+	(void)start;
+	if (!slen)
+		return fail("Sequence #%d is empty", index1);
+	if (!length_ok(slen, gap))
+		return fail("Sequence #%d exceeds length limits", index1);
+	if (b->sum + slen + 1 > INT32_MAX)
+		return fail("Length overflow after %d sequences", index1);
+	b->max = slen > b->max ? slen : b->max;
+	b->sum += slen + 1;
+	*b->w++ = 0;
+	b->num++;
+	return 0;
+}
+
+/* ---- FASTA (reference src/io/source/fasta.c:16-85) ---------------------------------------- */
+static int parse_fasta(uint8_t *file, const uint8_t *fend, const int32_t *lut, int32_t gap, struct builder *b)
+{
+	const uint8_t *p = file;
+	if (p >= fend || *p != '>')
+		return fail("Data before first header");
+	while (p < fend) {
+		while (p < fend && *p != '\n' && *p != '\r') /* header line */
+			p++;
+		while (p < fend && (*p == '\n' || *p == '\r'))
+			p++;
+		if (p >= fend)
+			return fail("Last header has no data");
+		const uint8_t *body = p;
+		while (p < fend && *p != '>')
+			p++;
+		/* the body is consumed before the write cursor can reach it: w <= body always */
+		if (add_sequence(b, body, (size_t)(p - body), false, lut, gap, b->num + 1))
+			return 1;
+	}
+	return 0;
+}
+
+/* ---- DSV (reference src/io/source/dsv.c:26-230) ------------------------------------------- */
+static const uint8_t *dsv_field(const uint8_t **cur, const uint8_t *end, uint8_t delim, int32_t *flen)
+{
+	const uint8_t *p = *cur, *start = p;
+	bool quoted = false;
+	while (p < end) {
+		if (*p == '"') {
+			if (quoted && p + 1 < end && p[1] == '"') {
+				p += 2;
+				continue;
+			}
+			quoted = !quoted;
+			p++;
+			continue;
+		}
+		if (!quoted && (*p == delim || *p == '\n' || *p == '\r'))
+			break;
+		p++;
+	}
+	int32_t len = (int32_t)(p - start);
+	if (len >= 2 && *start == '"' && start[len - 1] == '"') {
+		len -= 2;
+		start++;
+	}
+	*flen = len;
+	if (p < end && *p == delim)
+		p++;
+	*cur = p;
+	return start;
+}
+
+static int32_t dsv_columns(const uint8_t *p, const uint8_t *end, uint8_t delim)
+{
+	int32_t count = 1;
+	bool quoted = false;
+	while (p < end) {
+		if (*p == '"') {
+			if (quoted && p + 1 < end && p[1] == '"') {
+				p += 2;
+				continue;
+			}
+			quoted = !quoted;
+		} else if (*p == delim && !quoted) {
+			count++;
+		}
+		if (!quoted && (*p == '\n' || *p == '\r'))
+			break;
+		p++;
+	}
+	return count;
+}
+
+static int parse_dsv(uint8_t *file, const uint8_t *fend, uint8_t delim, const int32_t *lut, int32_t gap,
+		     int dsv_column, int dsv_has_header, struct builder *b)
+{
+	static const char *KEYS[] = { "sequence", "seq", "protein", "dna", "rna", "amino", "peptide", "chain", NULL };
+	const uint8_t *p = file;
+	const int32_t cols = dsv_columns(p, fend, delim);
+	int32_t seq_col = -1;
+	for (int32_t col = 0; col < cols; col++) {
+		int32_t flen;
+		const uint8_t *f = dsv_field(&p, fend, delim, &flen);
+		if (!flen)
+			return fail("First row has empty column");
+		for (const char **key = KEYS; *key && seq_col < 0; key++)
+			if ((size_t)flen == strlen(*key) && !strncasecmp((const char *)f, *key, (size_t)flen))
+				seq_col = col;
+	}
+	while (p < fend && (*p == '\n' || *p == '\r'))
+		p++;
+	if (seq_col < 0) {
+		/* the reference asks the user here (dsv.c:139-151) */
+		if (dsv_column < 0 || dsv_column >= cols)
+			return fail("No sequence column found in the header (sequence, seq, protein, dna, rna, amino, "
+				    "peptide, chain); pass --column N [--no-header]");
+		seq_col = dsv_column;
+		if (!dsv_has_header)
+			p = file;
+	}
+	while (p < fend) {
+		while (p < fend && (*p == '\n' || *p == '\r'))
+			p++;
+		if (p >= fend)
+			break;
+		const int32_t row = b->num + 1;
+		int32_t flen = 0;
+		for (int32_t col = 0; col < seq_col; col++) {
+			dsv_field(&p, fend, delim, &flen);
+			if (p >= fend || *p == '\n' || *p == '\r')
+				return fail("DSV row #%d has no sequence column", row);
+		}
+		const uint8_t *f = dsv_field(&p, fend, delim, &flen);
+		if (!flen)
+			return fail("Sequence #%d is empty", row);
+		if (add_sequence(b, f, (size_t)flen, true, lut, gap, row))
+			return 1;
+		for (int32_t col = seq_col + 1; col < cols; col++) {
+			if (p >= fend || *p == '\n' || *p == '\r')
+				return fail("DSV row #%d has too few columns", row);
+			dsv_field(&p, fend, delim, &flen);
+		}
+		if (p < fend && *p != '\n' && *p != '\r')
+			return fail("DSV row #%d has too many columns", row);
+	}
+	return 0;
+}
+
+/* ---- input_load (reference src/io/input.c:28-93) ------------------------------------------ */
+static int build_store(uint8_t *file, size_t size, const char *ext, const int32_t *lut, int32_t gap, int dsv_column,
+		       int dsv_has_header, struct sa_host_store *out)
+{
+	static const char *FASTA_EXT[] = { "fasta", "fa", "fas", "fna", "ffn", "faa", "frn", "mpfa", NULL };
+	static const struct {
+		const char *ext;
+		uint8_t delim;
+	} DSV_EXT[] = { { "csv", ',' }, { "tsv", '\t' }, { "ssv", ';' }, { "psv", '|' }, { NULL, 0 } };
+	struct builder b = { .w = file, .base = file };
+	int rc = -1;
+	for (const char **e = FASTA_EXT; *e && rc < 0; e++)
+		if (!strcasecmp(*e, ext))
+			rc = parse_fasta(file, file + size, lut, gap, &b);
+	for (int k = 0; DSV_EXT[k].ext && rc < 0; k++)
+		if (!strcasecmp(DSV_EXT[k].ext, ext))
+			rc = parse_dsv(file, file + size, DSV_EXT[k].delim, lut, gap, dsv_column, dsv_has_header, &b);
+	if (rc < 0)
+		return fail("Unsupported file format: .%s", ext);
+	if (rc)
+		return 1;
+	if (b.num < 2)
+		return fail("Not enough sequences: %d (min: 2)", b.num);
+	struct sa_meta *meta = NULL;
+	if (posix_memalign((void **)&meta, 64, sizeof(*meta) * (size_t)b.num))
+		return fail("Out of memory for %d sequences", b.num);
+	const uint8_t *p = file;
+	for (int32_t k = 0; k < b.num; k++) {
+		const int32_t len = (int32_t)strlen((const char *)p);
+		meta[k] = (struct sa_meta){ (int32_t)(p - file), len };
+		p += len + 1;
+	}
+	out->in = (struct sa_input){ file, meta, b.max, b.num };
+	out->blob_bytes = (size_t)(p - file);
+	return 0;
+}
+
+int sa_host_parse(const uint8_t *data, size_t size, const char *ext, const int32_t lut[SA_LUT_SIZE],
+		  int32_t gap, int dsv_column, int dsv_has_header, struct sa_host_store *out)
+{
+	memset(out, 0, sizeof(*out));
+	uint8_t *copy = NULL;
+	if (size > INT32_MAX)
+		return fail("Input larger than 2 GiB");
+	if (posix_memalign((void **)&copy, 64, size + 64))
+		return fail("Out of memory reading input");
+	memcpy(copy, data, size);
+	memset(copy + size, 0, 64);
+	if (build_store(copy, size, ext, lut, gap, dsv_column, dsv_has_header, out)) {
+		free(copy);
+		return 1;
+	}
+	return 0;
+}
+
+int sa_host_load(const char *path, const int32_t lut[SA_LUT_SIZE], int32_t gap, int dsv_column, int dsv_has_header,
+		 struct sa_host_store *out)
+{
+	memset(out, 0, sizeof(*out));
+	const char *name = strrchr(path, '/');
+	name = name ? name + 1 : path;
+	const char *dot = strrchr(name, '.');
+	if (!dot || dot == name)
+		return fail("File extension not found: %s", name);
+	FILE *f = fopen(path, "rb");
+	if (!f)
+		return fail("Failed to open %s: %s", name, strerror(errno));
+	fseek(f, 0, SEEK_END);
+	const long sz = ftell(f);
+	fseek(f, 0, SEEK_SET);
+	if (sz < 0 || sz > INT32_MAX) {
+		fclose(f);
+		return fail("Input larger than 2 GiB: %s", name);
+	}
+	uint8_t *buf = NULL;
+	if (posix_memalign((void **)&buf, 64, (size_t)sz + 64)) {
+		fclose(f);
+		return fail("Out of memory reading %s", name);
+	}
+	if (fread(buf, 1, (size_t)sz, f) != (size_t)sz) {
+		fclose(f);
+		free(buf);
+		return fail("Failed to read %s", name);
+	}
+	fclose(f);
+	memset(buf + sz, 0, 64);
+	if (build_store(buf, (size_t)sz, dot + 1, lut, gap, dsv_column, dsv_has_header, out)) {
+		free(buf);
+		return 1;
+	}
+	return 0;
+}
+
+void sa_host_store_free(struct sa_host_store *s)
+{
+	free(s->in.meta);
+	free(s->in.seqs);
+	memset(s, 0, sizeof(*s));
+}
+
+/* ---- similarity filter (reference src/bio/filter.c:14-89, sequential semantics) ---------- */
+int32_t sa_host_filter(struct sa_host_store *s, float threshold, int threads)
+{
+	if (threshold <= 0.0f)
+		return s->in.num;
+	const int32_t num = s->in.num;
+	const uint8_t *seqs = s->in.seqs;
+	struct sa_meta *meta = s->in.meta;
+	uint8_t *lost = calloc((size_t)num, 1);
+	if (!lost) {
+		fail("Out of memory during sequence filtering");
+		return -1;
+	}
+#ifdef _OPENMP
+	if (threads > 0)
+		omp_set_num_threads(threads);
+#else
+	(void)threads;
+#endif
+	/* Blocked so that the result equals the sequential loop exactly: a block of later sequences is
+	 * first tested in parallel against every survivor BEFORE the block (their fate is final), then
+	 * the block is resolved against itself in order. */
+	const int32_t BLOCK = 256;
+	for (int32_t b0 = 1; b0 < num; b0 += BLOCK) {
+		const int32_t b1 = b0 + BLOCK < num ? b0 + BLOCK : num;
+#pragma omp parallel for schedule(dynamic, 4)
+		for (int32_t j = b0; j < b1; j++) {
+			const uint8_t *s1 = seqs + meta[j].off;
+			for (int32_t i = 0; i < b0 && !lost[j]; i++) {
+				if (lost[i])
+					continue;
+				const uint8_t *s2 = seqs + meta[i].off;
+				const int32_t ml = meta[j].len < meta[i].len ? meta[j].len : meta[i].len;
+				int32_t matches = 0;
+				for (int32_t k = 0; k < ml; k++)
+					matches += s1[k] == s2[k];
+				if ((float)matches / (float)ml >= threshold)
+					lost[j] = 1;
+			}
+		}
+		for (int32_t j = b0; j < b1; j++) {
+			if (lost[j])
+				continue;
+			const uint8_t *s1 = seqs + meta[j].off;
+			for (int32_t i = b0; i < j; i++) {
+				if (lost[i])
+					continue;
+				const uint8_t *s2 = seqs + meta[i].off;
+				const int32_t ml = meta[j].len < meta[i].len ? meta[j].len : meta[i].len;
+				int32_t matches = 0;
+				for (int32_t k = 0; k < ml; k++)
+					matches += s1[k] == s2[k];
+				if ((float)matches / (float)ml >= threshold) {
+					lost[j] = 1;
+					break;
+				}
+			}
+		}
+	}
+	int32_t kept = 0, used = 0, mx = 0;
+	for (int32_t r = 0; r < num; r++) {
+		if (lost[r])
+			continue;
+		struct sa_meta m = meta[r];
+		if (used != m.off)
+			memmove(s->in.seqs + used, s->in.seqs + m.off, (size_t)m.len + 1);
+		m.off = used;
+		used += m.len + 1;
+		meta[kept++] = m;
+		mx = m.len > mx ? m.len : mx;
+	}
+	free(lost);
+	s->in.num = kept;
+	s->in.max = mx;
+	s->blob_bytes = (size_t)used;
+	if (kept < 2) {
+		fail("Not enough sequences: %d (min: 2)", kept);
+		return -1;
+	}
+	return kept;
+}
+
+/* ---- result matrix (reference src/io/output.c:16-66, src/system/os.c:32-141,262-295) ------ */
+static size_t matrix_bytes(size_t num, bool triangular)
+{
+	return sizeof(int32_t) * (triangular ? num * (num - 1) / 2 : num * num);
+}
+
+int32_t *sa_host_matrix_alloc(size_t num, bool triangular)
+{
+	const size_t bytes = matrix_bytes(num, triangular);
+	void *p = mmap(NULL, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	if (p == MAP_FAILED) {
+		fail("Failed to allocate %.2f GiB for the similarity matrix", (double)bytes / (double)(1 << 30));
+		return NULL;
+	}
+	return p;
+}
+
+void sa_host_matrix_free(int32_t *m, size_t num, bool triangular)
+{
+	if (m)
+		munmap(m, matrix_bytes(num, triangular) ? matrix_bytes(num, triangular) : 1);
+}
+
+size_t sa_host_available_memory(void)
+{
+	FILE *f = fopen("/proc/meminfo", "r");
+	if (!f)
+		return 0;
+	char line[256];
+	size_t kb = 0;
+	while (fgets(line, sizeof(line), f))
+		if (sscanf(line, "MemAvailable: %zu kB", &kb) == 1)
+			break;
+	fclose(f);
+	return kb * 1024;
+}
+
+/* ---- HDF5 writer (reference src/io/format/hdf5.c:14-202) ---------------------------------- */
+size_t sa_host_hdf5_chunk_dim(size_t dim)
+{
+	if (dim <= 256) /* H5_MIN_CHUNK_SIZE: contiguous layout, -z ignored (hdf5.c:71) */
+		return dim;
+	size_t c = 64;
+	while (c < dim) /* the reference's byte target never updates: largest 64*2^k <= dim */
+		c *= 2;
+	if (c > dim)
+		c /= 2;
+	if (c < 256)
+		c = 256;
+	if (c > 4096)
+		c = 4096;
+	return c < dim ? c : dim;
+}
+
+int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const int32_t *matrix, bool triangular,
+		       unsigned compression)
+{
+	const size_t dim = (size_t)s->in.num;
+	int rc = 1;
+	hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
+	H5Pset_libver_bounds(fapl, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST);
+	H5Pset_alignment(fapl, 4096, 4096);
+	hid_t file = H5Fcreate(path, H5F_ACC_TRUNC, H5P_DEFAULT, fapl);
+	H5Pclose(fapl);
+	if (file < 0)
+		return fail("Failed to create HDF5 file: %s", path);
+
+	/* /sequences: 1-D, N variable-length C strings */
+	const char **strs = malloc(sizeof(*strs) * dim);
+	if (!strs) {
+		H5Fclose(file);
+		return fail("Out of memory allocating output sequence data");
+	}
+	for (size_t k = 0; k < dim; k++)
+		strs[k] = (const char *)(s->in.seqs + s->in.meta[k].off);
+	hsize_t sd[1] = { dim };
+	hid_t sspace = H5Screate_simple(1, sd, NULL);
+	hid_t stype = H5Tcopy(H5T_C_S1);
+	H5Tset_size(stype, H5T_VARIABLE);
+	hid_t sset = H5Dcreate2(file, "/sequences", stype, sspace, H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT);
+	herr_t st = sset < 0 ? -1 : H5Dwrite(sset, stype, H5S_ALL, H5S_ALL, H5P_DEFAULT, strs);
+	if (sset >= 0)
+		H5Dclose(sset);
+	H5Sclose(sspace);
+	H5Tclose(stype);
+	free(strs);
+	if (st < 0) {
+		H5Fclose(file);
+		return fail("Failed to write sequence data to HDF5 dataset");
+	}
+
+	/* /similarity_matrix: N x N int32 little endian */
+	hsize_t md[2] = { dim, dim };
+	hid_t mspace = H5Screate_simple(2, md, NULL);
+	hid_t plist = H5Pcreate(H5P_DATASET_CREATE);
+	const size_t chunk = sa_host_hdf5_chunk_dim(dim);
+	if (dim > 256) {
+		hsize_t cd[2] = { chunk, chunk };
+		H5Pset_chunk(plist, 2, cd);
+		if (compression)
+			H5Pset_deflate(plist, compression);
+	}
+	hid_t mset = H5Dcreate2(file, "/similarity_matrix", H5T_STD_I32LE, mspace, H5P_DEFAULT, plist, H5P_DEFAULT);
+	H5Pclose(plist);
+	H5Sclose(mspace);
+	if (mset < 0) {
+		H5Fclose(file);
+		return fail("Failed to create HDF5 dataset for Similarity Matrix");
+	}
+	if (!triangular) {
+		st = H5Dwrite(mset, H5T_NATIVE_INT32, H5S_ALL, H5S_ALL, H5P_DEFAULT, matrix);
+		rc = st < 0 ? fail("Failed to write Similarity Matrix to HDF5") : 0;
+	} else {
+		/* expand `rows` rows at a time; unlike hdf5.c:152-162 the diagonal is written as 0 */
+		size_t rows = chunk > 4 ? chunk : 4;
+		const size_t avail = sa_host_available_memory();
+		if (avail && rows * dim * 4 * 4 > avail && avail / (16 * dim) > 4)
+			rows = avail / (16 * dim);
+		int32_t *buf = malloc(sizeof(int32_t) * rows * dim);
+		hid_t fspace = H5Dget_space(mset);
+		rc = 0;
+		if (!buf)
+			rc = fail("Out of memory during HDF5 conversion");
+		for (size_t off = 0; off < dim && !rc; off += rows) {
+			const size_t end = off + rows < dim ? off + rows : dim;
+#pragma omp parallel for schedule(static)
+			for (size_t i = off; i < end; i++) {
+				int32_t *row = buf + dim * (i - off);
+				for (size_t j = 0; j < i; j++)
+					row[j] = matrix[i * (i - 1) / 2 + j];
+				row[i] = 0;
+				for (size_t j = i + 1; j < dim; j++)
+					row[j] = matrix[j * (j - 1) / 2 + i];
+			}
+			hsize_t start[2] = { off, 0 }, count[2] = { end - off, dim };
+			H5Sselect_hyperslab(fspace, H5S_SELECT_SET, start, NULL, count, NULL);
+			hid_t mem = H5Screate_simple(2, count, NULL);
+			st = H5Dwrite(mset, H5T_NATIVE_INT32, mem, fspace, H5P_DEFAULT, buf);
+			H5Sclose(mem);
+			if (st < 0)
+				rc = fail("Failed to write chunk to HDF5");
+		}
+		if (fspace >= 0)
+			H5Sclose(fspace);
+		free(buf);
+	}
+	H5Dclose(mset);
+	H5Fclose(file);
+	return rc;
+}

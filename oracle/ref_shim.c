@@ -91,6 +91,19 @@ int ref_align(uchar *seqs, struct meta *meta, s32 num, s32 max, s32 *matrix,
 	return align(in, out) ? 0 : 1;
 }
 
+/* Reference HDF5 writer (output_flush -> flush_hdf5, src/io/output.c:89-99, src/io/format/hdf5.c:14-202)
+ * into the -o path given at configuration time; compression level from -z. */
+int ref_flush(uchar *seqs, struct meta *meta, s32 num, s32 *matrix, int triangular)
+{
+	const char **ptrs = malloc(sizeof(*ptrs) * (size_t)num);
+	for (s32 i = 0; i < num; i++)
+		ptrs[i] = (const char *)(seqs + meta[i].off);
+	struct output out = { .matrix = matrix, .seqs = ptrs, .dim = (size_t)num, .triangular = triangular != 0 };
+	bool ok = output_flush(&out);
+	free(ptrs);
+	return ok ? 0 : 1;
+}
+
 /* Reference similarity filter (-f), threshold comes from the parsed argv.
  * Compacts seqs/meta in place, returns the surviving count (or -1). */
 int ref_filter(uchar *seqs, struct meta *meta, s32 *num, s32 *max)

@@ -101,7 +101,7 @@ class RefLib:
     reference's option parser keeps per-process state)."""
 
     def __init__(self, method: str, matrix: str, gap_pen=None, gap_open=None, gap_extend=None, threads: int = 0,
-                 filter_threshold: float | None = None):
+                 filter_threshold: float | None = None, compression: int | None = None):
         if not REF_SO.exists():
             raise FileNotFoundError(REF_SO)
         self._tmpdir = tempfile.mkdtemp(prefix="saref_")
@@ -122,6 +122,9 @@ class RefLib:
             argv += ["-T", str(threads)]
         if filter_threshold is not None:
             argv += ["-f", repr(float(filter_threshold))]
+        if compression is not None:
+            argv += ["-z", str(compression)]
+        self.output_path = pathlib.Path(self._tmpdir) / "out.h5"
         self.lib = C.CDLL(str(so))
         arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])
         self._argv = arr
@@ -161,6 +164,15 @@ class RefLib:
         kept = self.lib.ref_filter(blob.ctypes.data, meta.ctypes.data, C.byref(num), C.byref(mx))
         assert kept >= 0
         return [blob[meta[k, 0]:meta[k, 0] + meta[k, 1]].tobytes() for k in range(kept)]
+
+    def flush_hdf5(self, store, matrix: np.ndarray, triangular: bool) -> pathlib.Path:
+        """The reference's own HDF5 writer on a given result matrix -> path of the file it wrote."""
+        blob, meta = store.blob.copy(), store.meta.copy()
+        m = np.ascontiguousarray(matrix, np.int32).reshape(-1).copy()
+        self.lib.ref_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int]
+        rc = self.lib.ref_flush(blob.ctypes.data, meta.ctypes.data, store.num, m.ctypes.data, int(triangular))
+        assert rc == 0
+        return self.output_path
 
     def close(self):
         shutil.rmtree(self._tmpdir, ignore_errors=True)

@@ -1,0 +1,131 @@
+"""CPU: the C host around the device boundary (cli/sa_host.c) -- FASTA/DSV parsing, similarity filter,
+HDF5 writer -- against the reference's documented behaviour, its golden filter result, and (where
+oracle/_ref exists) the reference's own HDF5 writer via h5diff."""
+import json
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.golden_util import GOLDEN_DIR, load_case, tri_to_full
+from tests.host_binding import H5DIFF, H5DUMP, Host, HostError, h5_matrix, h5_sequences
+from tests.oracle_binding import RefLib, ref_available
+
+
+@pytest.fixture(scope="module")
+def host():
+    return Host()
+
+
+@pytest.fixture(scope="module")
+def amino_lut(sa):
+    return sa.Scoring.from_names("nw", "blosum62", gap_pen=4).lut
+
+
+@pytest.fixture(scope="module")
+def dna_lut(sa):
+    return sa.Scoring.from_names("nw", "nuc44", gap_pen=4).lut
+
+
+def test_fasta_parsing(host, amino_lut):
+    data = b">one desc\r\nARND\r\ncqeg\r\n>two\nHIL K\n\n>three\nW\n"
+    assert host.parse_sequences(data, "fasta", amino_lut) == [b"ARNDCQEG", b"HILK", b"W"]
+    for ext in ("fa", "FAS", "fna", "ffn", "faa", "frn", "mpfa"):  # fasta.c:12-14, case-insensitive
+        assert host.parse_sequences(b">a\nAR\n>b\nND\n", ext, amino_lut) == [b"AR", b"ND"]
+    for bad, msg in ((b"ARND\n>a\nAR\n", "Data before first header"), (b">a\nAR\n>b\n", "Last header has no data"),
+                     (b">a\nAR\n>b\n>c\nAR\n", "Sequence #2 is empty"), (b">a\nAR\n>b\nAJ\n", "Sequence #2 is invalid"),
+                     (b">a\nAR\n", "Not enough sequences"), (b">a\nA\xe9\n>b\nA\n", "Sequence #1 is corrupted")):
+        with pytest.raises(HostError, match=msg):
+            host.parse_sequences(bad, "fasta", amino_lut)
+    with pytest.raises(HostError, match="Unsupported file format"):
+        host.parse_sequences(b">a\nAR\n>b\nND\n", "txt", amino_lut)
+    # length limit len <= ((2^31-2)/2)/gap (io/input.c:15-19)
+    with pytest.raises(HostError, match="exceeds length limits"):
+        host.parse_sequences(b">a\n" + b"A" * 50 + b"\n>b\nA\n", "fasta", amino_lut, gap=-(2**26))
+
+
+def test_dsv_parsing(host, amino_lut, dna_lut):
+    csv = b'id,Sequence,note\n1,arnd,"x, y"\n2,"CQ EG",z\r\n3,W,"say ""hi"""\n'
+    assert host.parse_sequences(csv, "csv", amino_lut) == [b"ARND", b"CQEG", b"W"]
+    assert host.parse_sequences(b"name\tdna\nx\tACGT\ny\tGGN\n", "tsv", dna_lut) == [b"ACGT", b"GGN"]
+    assert host.parse_sequences(b"seq;k\nAR;1\nND;2\n", "ssv", amino_lut) == [b"AR", b"ND"]
+    assert host.parse_sequences(b"k|peptide\n1|AR\n2|ND\n", "psv", amino_lut) == [b"AR", b"ND"]
+    # no recognised header name: needs the answer the reference would prompt for (dsv.c:139-151)
+    with pytest.raises(HostError, match="No sequence column"):
+        host.parse_sequences(b"a,b\n1,AR\n2,ND\n", "csv", amino_lut)
+    assert host.parse_sequences(b"a,b\n1,AR\n2,ND\n", "csv", amino_lut, column=1) == [b"AR", b"ND"]
+    assert host.parse_sequences(b"1,AR\n2,ND\n", "csv", amino_lut, column=1, has_header=False) == [b"AR", b"ND"]
+    for bad, msg in ((b"id,seq\n1,AR\n2\n", "no sequence column"), (b"id,seq,x\n1,AR\n", "too few columns"),
+                     (b"id,seq\n1,AR,9\n2,ND\n", "too many columns"), (b"id,seq,x\n1,,9\n2,ND,8\n", "Sequence #1 is empty"),
+                     (b"id,seq\n1,AR\n2,N1\n", "Sequence #2 is invalid")):
+        with pytest.raises(HostError, match=msg):
+            host.parse_sequences(bad, "csv", amino_lut)
+
+
+def test_filter_matches_reference_golden_and_oracle(host, oracle, sa, amino_lut):
+    z = np.load(GOLDEN_DIR / "filter_f0.9.npz")
+    meta = np.ascontiguousarray(z["meta"], np.int32)
+    store = sa.SequenceStore(blob=np.ascontiguousarray(z["blob"]), meta=meta, num=meta.shape[0], max=int(meta[:, 1].max()))
+    seqs = [store.sequence(k) for k in range(store.num)]
+    thr = json.loads(str(z["params"]))["threshold"]
+    want = [seqs[k] for k in z["kept"]]
+    for threads in (1, 4):
+        assert host.filter(seqs, amino_lut, thr, threads) == want
+    # block boundaries of the blocked implementation: > 256 sequences, duplicates straddling blocks
+    from tests.synth import make_near_duplicates, make_protein_set
+    big = make_near_duplicates(make_protein_set(700, 30, 60, 9), 0.3, 0.05, 9)
+    st = sa.SequenceStore.from_sequences(big)
+    keep = oracle.filter(st, 0.9)
+    assert 0 < keep.sum() < len(big)
+    assert host.filter(big, amino_lut, 0.9, 3) == [s for s, k in zip(big, keep) if k]
+    assert host.filter(big, amino_lut, 0.0) == big
+
+
+def test_hdf5_chunk_rule(host):
+    # hdf5.c:70-84: contiguous up to 256; else clamp(largest 64*2^k <= N, 256, 4096)
+    assert [host.chunk_dim(n) for n in (2, 100, 256, 257, 300, 511, 512, 1000, 1024, 5000, 8192, 100000)] == \
+        [2, 100, 256, 256, 256, 256, 512, 512, 1024, 4096, 4096, 4096]
+
+
+@pytest.mark.skipif(not H5DUMP.exists(), reason="h5dump not available")
+def test_hdf5_roundtrip_full_and_triangular(host, tmp_path, amino_lut):
+    store, scoring, expected, full = load_case("cfg1_nw_blosum62_p4")
+    seqs = [store.sequence(k) for k in range(store.num)]
+    want = tri_to_full(expected, store.num)
+    for tri, z in ((False, 0), (True, 0), (True, 6)):
+        path = tmp_path / f"out_{int(tri)}_{z}.h5"
+        host.write_hdf5(path, seqs, amino_lut, expected if tri else want, tri, z)
+        assert np.array_equal(h5_matrix(path, store.num), want)
+        assert h5_sequences(path) == seqs
+    # chunked + deflate path (N > 256), packed input, diagonal must be written as zeros
+    n = 300
+    rng = np.random.default_rng(3)
+    tri = rng.integers(-50, 50, n * (n - 1) // 2, dtype=np.int32)
+    seqs300 = [bytes(rng.choice(list(b"ARNDCQEG"), 5).astype(np.uint8)) for _ in range(n)]
+    path = tmp_path / "big.h5"
+    host.write_hdf5(path, seqs300, amino_lut, tri, True, 6)
+    assert np.array_equal(h5_matrix(path, n), tri_to_full(tri, n))
+    hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
+    assert "CHUNKED ( 256, 256 )" in hdr and "DEFLATE { LEVEL 6 }" in hdr and "H5T_STD_I32LE" in hdr
+
+
+@pytest.mark.skipif(not (ref_available() and H5DIFF.exists()), reason="needs oracle/_ref and h5diff")
+@pytest.mark.parametrize("n,z", [(100, 0), (300, 6)])
+def test_hdf5_equals_reference_writer(host, tmp_path, amino_lut, sa, oracle, n, z):
+    from tests.synth import make_protein_set
+    seqs = make_protein_set(n, 5, 20, 13)
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
+    full = oracle.align(store, scoring, triangular=False)
+    ref = RefLib("nw", "blosum62", gap_pen=4, compression=z)
+    try:
+        ref_path = ref.flush_hdf5(store, full, triangular=False)
+        mine = tmp_path / "mine.h5"
+        host.write_hdf5(mine, seqs, amino_lut, full, False, z)
+        res = subprocess.run([str(H5DIFF), str(ref_path), str(mine)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
+        props = lambda p: [l.strip() for l in subprocess.run([str(H5DUMP), "-H", "-p", str(p)], capture_output=True, text=True).stdout.splitlines()
+                           if any(k in l for k in ("CHUNKED", "DEFLATE", "CONTIGUOUS", "DATATYPE", "DATASPACE"))]
+        assert props(ref_path) == props(mine)
+    finally:
+        ref.close()
