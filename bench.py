@@ -109,7 +109,7 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("SA_BENCH_FORCE_DIST"):  # the env switch rehearses the RCCL path on one GPU
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 

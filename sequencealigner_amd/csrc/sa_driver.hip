@@ -863,7 +863,14 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 			ndev = want;
 	}
 	const int64_t pairs = (int64_t)in.num * (in.num - 1) / 2;
-	if (pairs < (int64_t)ndev * 4096)
+	/* SA_HIP_SPLIT=n (testing aid): run the multi-device code path with n work-balanced slices even when
+	 * fewer devices are visible -- slice k goes to device k mod visible */
+	int nvisible = ndev, split = 0;
+	if (const char *env = getenv("SA_HIP_SPLIT"))
+		split = atoi(env);
+	if (split >= 2 && pairs >= split)
+		ndev = split;
+	else if (pairs < (int64_t)ndev * 4096)
 		ndev = 1;
 	if (ndev == 1) {
 		std::string err;
@@ -883,8 +890,8 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 	std::vector<char> oks((size_t)ndev, 0);
 	for (int d = 0; d < ndev; d++)
 		threads.emplace_back([&, d]() {
-			oks[(size_t)d] = run_device_range(d, in, out, *sc, bounds[(size_t)d], bounds[(size_t)d + 1],
-							  false, errs[(size_t)d]);
+			oks[(size_t)d] = run_device_range(d % nvisible, in, out, *sc, bounds[(size_t)d],
+							  bounds[(size_t)d + 1], false, errs[(size_t)d]);
 		});
 	for (auto &t : threads)
 		t.join();

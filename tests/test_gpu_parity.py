@@ -75,6 +75,21 @@ def test_edge_shapes(sa, oracle):
             assert np.array_equal(sa.hip_align(store, sc, triangular=False), oracle.align(store, sc, triangular=False))
 
 
+def test_multi_device_driver_path(sa, oracle, monkeypatch):
+    """sa_hip_align's several-devices-in-one-process path (work-balanced slices, one host thread per slice,
+    slices delivered straight into the host matrix), exercised on one GPU through SA_HIP_SPLIT."""
+    store = sa.SequenceStore.from_sequences(make_protein_set(400, 10, 200, 23))
+    for method, gaps in (("nw", dict(gap_pen=4)), ("sw", dict(gap_open=10, gap_extend=1))):
+        scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+        want_tri = oracle.align(store, scoring, triangular=True)
+        want_full = oracle.align(store, scoring, triangular=False)
+        for split in ("3", "8"):
+            monkeypatch.setenv("SA_HIP_SPLIT", split)
+            assert np.array_equal(sa.hip_align(store, scoring, triangular=True), want_tri)
+            assert np.array_equal(sa.hip_align(store, scoring, triangular=False), want_full)
+        monkeypatch.delenv("SA_HIP_SPLIT")
+
+
 def test_error_behaviour(sa):
     sc = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
     with pytest.raises(sa.AlignError, match="Not enough sequences"):
