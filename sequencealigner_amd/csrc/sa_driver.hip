@@ -36,11 +36,15 @@ struct sa_ctx {
 	int generic_blocks = 0;
 	unsigned *d_counters = nullptr; /* one tile counter per systolic class launch */
 	int persistent_wgs = 0;         /* workgroups of a persistent systolic launch  */
+	/* the class launches of one range run concurrently on side streams (their tails overlap) */
+	enum { NSIDE = 4 };
+	hipStream_t side[NSIDE] = {};
+	hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {};
 	/* systolic fast path: parameters and validity (see systolic_setup) */
 	bool sys_ok = false;
 	int32_t sys_pconst = 0, sys_q = 0;
 	int64_t sys_gain = 0, sys_slack = 0;
-	/* launch plan of the most recent packed range (bench loops over the same range) */
+	/* launch plans of recently used packed ranges (callers loop over the same few ranges) */
 	struct ClassLaunch {
 		int cls = 0;
 		int32_t ncols = 0, ntiles = 0;
@@ -49,9 +53,14 @@ struct sa_ctx {
 	};
 	struct Plan {
 		int64_t start = -1, count = -1;
+		int32_t chunk = SA_SYS_CHUNK; /* sequences per group stream chosen for this range */
 		std::vector<ClassLaunch> classes;
 		std::vector<std::pair<int64_t, int64_t>> generic; /* (start, count) runs for the generic kernels */
-	} plan;
+		uint64_t stamp = 0;
+	};
+	std::vector<Plan> plans;  /* small LRU cache */
+	Plan *plan = nullptr;     /* plan of the current sa_ctx_align_range call */
+	uint64_t plan_clock = 0;
 	/* instrumentation: one HIP-event pair per kernel launch, keyed by kernel name */
 	bool timing = false;
 	struct Timed {
@@ -62,13 +71,21 @@ struct sa_ctx {
 	std::vector<Timed> events;
 };
 
-static void plan_release(sa_ctx *ctx)
+static void plan_free(sa_ctx::Plan &pl)
 {
-	for (auto &c : ctx->plan.classes) {
+	for (auto &c : pl.classes) {
 		(void)hipFree(c.d_jlist);
 		(void)hipFree(c.d_tprefix);
 	}
-	ctx->plan = sa_ctx::Plan();
+	pl = sa_ctx::Plan();
+}
+
+static void plan_release(sa_ctx *ctx)
+{
+	for (auto &pl : ctx->plans)
+		plan_free(pl);
+	ctx->plans.clear();
+	ctx->plan = nullptr;
 }
 
 static bool device_ready(int device)
@@ -311,6 +328,16 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * SA_SYS_NCLASSES), break);
 		ctx->persistent_wgs = prop.multiProcessorCount * 32;
+		bool streams_ok = true;
+		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming), streams_ok = false);
+		for (int k = 0; k < sa_ctx::NSIDE && streams_ok; k++) {
+			SA_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking), streams_ok = false);
+			if (streams_ok) {
+				SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming), streams_ok = false);
+			}
+		}
+		if (!streams_ok)
+			break;
 		ok = true;
 	} while (0);
 	if (!ok) {
@@ -337,6 +364,14 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 	(void)hipFree(ctx->d_sub8);
 	(void)hipFree(ctx->d_scratch);
 	(void)hipFree(ctx->d_counters);
+	for (int k = 0; k < sa_ctx::NSIDE; k++) {
+		if (ctx->side[k])
+			(void)hipStreamDestroy(ctx->side[k]);
+		if (ctx->join_ev[k])
+			(void)hipEventDestroy(ctx->join_ev[k]);
+	}
+	if (ctx->fork_ev)
+		(void)hipEventDestroy(ctx->fork_ev);
 	delete ctx;
 }
 
@@ -485,9 +520,24 @@ extern "C" int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64
 
 static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 {
-	if (ctx->plan.start == start && ctx->plan.count == count)
-		return true;
-	plan_release(ctx);
+	for (auto &pl : ctx->plans)
+		if (pl.start == start && pl.count == count) {
+			pl.stamp = ++ctx->plan_clock;
+			ctx->plan = &pl;
+			return true;
+		}
+	constexpr size_t MAX_PLANS = 32;
+	if (ctx->plans.capacity() < MAX_PLANS)
+		ctx->plans.reserve(MAX_PLANS); /* pointers into the vector stay valid */
+	if (ctx->plans.size() >= MAX_PLANS) { /* evict the least recently used (hipFree waits for its users) */
+		size_t victim = 0;
+		for (size_t k = 1; k < ctx->plans.size(); k++)
+			if (ctx->plans[k].stamp < ctx->plans[victim].stamp)
+				victim = k;
+		plan_free(ctx->plans[victim]);
+		ctx->plans.erase(ctx->plans.begin() + (long)victim);
+	}
+	ctx->plan = nullptr;
 	const int64_t end = start + count;
 	std::vector<std::vector<int32_t>> jl((size_t)SA_SYS_NCLASSES), tp((size_t)SA_SYS_NCLASSES);
 	std::vector<int64_t> cpairs((size_t)SA_SYS_NCLASSES, 0), ccells((size_t)SA_SYS_NCLASSES, 0);
@@ -495,6 +545,16 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 	for (int32_t k = 0; k < ctx->num; k++)
 		lenpre[(size_t)k + 1] = lenpre[(size_t)k] + ctx->meta[(size_t)k].len;
 	sa_ctx::Plan plan;
+	/* Tile granularity: a wave-tile streams `chunk` sequences per lane group.  64 amortizes the per-tile
+	 * setup best; small ranges (one rank's share at 8 GPUs, a super-chunk of an overlapped schedule) get
+	 * shorter streams so that there are still several tiles per wave slot. */
+	{
+		const int64_t want_tiles = (int64_t)ctx->persistent_wgs * 6;
+		int32_t chunk = SA_SYS_CHUNK;
+		while (chunk > 8 && count / (4 * chunk) < want_tiles)
+			chunk >>= 1;
+		plan.chunk = chunk;
+	}
 	const int32_t j0 = column_of(start), j1 = column_of(end - 1);
 	for (int32_t j = j0; j <= j1; j++) {
 		const int64_t tri = (int64_t)j * (j - 1) / 2;
@@ -510,7 +570,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 				plan.generic.emplace_back(tri + ia, ib - ia);
 			continue;
 		}
-		const int rows = (64 / SA_SYS_CLASSES[cls].G) * SA_SYS_CHUNK;
+		const int rows = (64 / SA_SYS_CLASSES[cls].G) * plan.chunk;
 		if (tp[(size_t)cls].empty())
 			tp[(size_t)cls].push_back(0);
 		const int64_t tiles = (ib - ia + rows - 1) / rows;
@@ -549,10 +609,14 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 	}
 	plan.start = start;
 	plan.count = count;
-	ctx->plan = plan;
-	if (!ok)
-		plan_release(ctx);
-	return ok;
+	plan.stamp = ++ctx->plan_clock;
+	if (!ok) {
+		plan_free(plan);
+		return false;
+	}
+	ctx->plans.push_back(plan);
+	ctx->plan = &ctx->plans.back();
+	return true;
 }
 
 static const char *const METHOD_TAG[] = { "nw", "ga", "sw" };
@@ -587,11 +651,23 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		return true;
 	};
 
-	/* systolic streaming kernels: one persistent launch per column-length class */
-	if (!ctx->plan.classes.empty()) {
+	/* systolic streaming kernels: one persistent launch per column-length class; with several classes the
+	 * launches go to side streams forked from / joined back into the caller's stream so they run concurrently */
+	const bool fan_out = ctx->plan->classes.size() > 1 && !getenv("SA_HIP_SERIAL_CLASSES");
+	if (!ctx->plan->classes.empty()) {
 		SA_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * SA_SYS_NCLASSES, s), return 1);
 	}
-	for (const auto &cl : ctx->plan.classes) {
+	if (fan_out) {
+		SA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s), return 1);
+	}
+	hipStream_t caller = s;
+	int launch_no = 0;
+	for (const auto &cl : ctx->plan->classes) {
+		const int side_k = launch_no++ % sa_ctx::NSIDE;
+		if (fan_out) {
+			s = ctx->side[side_k];
+			SA_HIP_CHECK(hipStreamWaitEvent(s, ctx->fork_ev, 0), return 1);
+		}
 		const int W = SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
 		SaSysArgs a{};
 		a.codes = ctx->d_codes;
@@ -611,6 +687,7 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.gap_e = ctx->sc.gap_ext;
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
 		a.counter = ctx->d_counters + cl.cls;
+		a.chunk = ctx->plan->chunk;
 		char name[64];
 		snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
 			 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
@@ -642,10 +719,15 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		}
 		if (!timed_end(name, e0, e1, cl.pairs, cl.cells))
 			return 1;
+		if (fan_out) {
+			SA_HIP_CHECK(hipEventRecord(ctx->join_ev[side_k], s), return 1);
+			SA_HIP_CHECK(hipStreamWaitEvent(caller, ctx->join_ev[side_k], 0), return 1);
+		}
 	}
+	s = caller;
 
 	/* everything the fast path does not cover: pair-per-wave kernels on contiguous packed runs */
-	for (const auto &run : ctx->plan.generic) {
+	for (const auto &run : ctx->plan->generic) {
 		SaGenericArgs a{};
 		a.st.codes = ctx->d_codes;
 		a.st.meta = ctx->d_meta;

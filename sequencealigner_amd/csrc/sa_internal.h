@@ -76,6 +76,7 @@ struct SaSysArgs {
 	int32_t q;               /* GA: o - e (<= 0); else 0                                              */
 	int32_t gap_g, gap_o, gap_e;
 	int32_t delta;           /* baseline raise per sequence                                           */
+	int32_t chunk;           /* sequences per group stream of a wave-tile, 1..SA_SYS_CHUNK            */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */

@@ -163,8 +163,9 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	const int64_t tri = (int64_t)j * (j - 1) / 2;
 	const int64_t ia64 = A.start > tri ? A.start - tri : 0;
 	const int64_t ib64 = A.end - tri < j ? A.end - tri : j;
-	const int32_t i_begin = (int32_t)ia64 + chunk * (NG * CH);
-	const int32_t i_count = (int32_t)ib64 - i_begin < NG * CH ? (int32_t)ib64 - i_begin : NG * CH;
+	const int32_t ch = A.chunk; /* sequences per group stream (<= CH): shorter tiles when the range is small */
+	const int32_t i_begin = (int32_t)ia64 + chunk * (NG * ch);
+	const int32_t i_count = (int32_t)ib64 - i_begin < NG * ch ? (int32_t)ib64 - i_begin : NG * ch;
 	const int32_t offj = A.off[j];
 	const int32_t n = A.off[j + 1] - offj - 1;
 
@@ -213,17 +214,17 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	__syncthreads();
 
 	/* ---- row streams: group g streams sequences [ib_g, ib_g + cnt_g) ---- */
-	const int32_t ib_g = i_begin + grp * CH;
-	int32_t cnt_g = i_count - grp * CH;
-	cnt_g = cnt_g < 0 ? 0 : cnt_g > CH ? CH : cnt_g;
+	const int32_t ib_g = i_begin + grp * ch;
+	int32_t cnt_g = i_count - grp * ch;
+	cnt_g = cnt_g < 0 ? 0 : cnt_g > ch ? ch : cnt_g;
 	const int32_t sbeg = A.off[ib_g < A.num ? ib_g : 0];
 	const int32_t slen = cnt_g > 0 ? A.off[ib_g + cnt_g] - sbeg : 0;
 	int32_t smax = 0; /* longest stream of the wave */
 #pragma unroll
 	for (int g = 0; g < NG; g++) {
-		int32_t c = i_count - g * CH;
-		c = c < 0 ? 0 : c > CH ? CH : c;
-		const int32_t b = i_begin + g * CH;
+		int32_t c = i_count - g * ch;
+		c = c < 0 ? 0 : c > ch ? ch : c;
+		const int32_t b = i_begin + g * ch;
 		const int32_t l = c > 0 ? A.off[b + c] - A.off[b] : 0;
 		smax = l > smax ? l : smax;
 	}
@@ -451,10 +452,10 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	/* ---- epilogue: un-bias and store, 64 consecutive packed indices per group ---- */
 #pragma unroll
 	for (int g = 0; g < NG; g++) {
-		int32_t c = i_count - g * CH;
-		c = c < 0 ? 0 : c > CH ? CH : c;
+		int32_t c = i_count - g * ch;
+		c = c < 0 ? 0 : c > ch ? ch : c;
 		if (lane < c && active) {
-			const int32_t i = i_begin + g * CH + lane;
+			const int32_t i = i_begin + g * ch + lane;
 			const int32_t m = A.off[i + 1] - A.off[i] - 1;
 			const int32_t raw = s_out[g * CH + lane] - lane * delta;
 			int32_t score;

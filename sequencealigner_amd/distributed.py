@@ -25,3 +25,31 @@ def gather_packed(dist, packed, rank: int, per: int):
         world = packed.numel() // per
         dist.all_gather([packed[r * per:(r + 1) * per] for r in range(world)], mine.clone())
     return packed
+
+
+class ChunkedGather:
+    """Strong-scaling schedule that overlaps the RCCL all-gather with the kernels.
+
+    The packed index is cut into `chunks` super-chunks and every super-chunk into `world` equal slices
+    (chunk-major, rank-minor), so super-chunk c of the result is exactly the concatenation over ranks of
+    what they computed for it: `all_gather_into_tensor(buffer[c], my_slice)` lands in place in packed
+    order.  Rank r scores slice (c, r) on the compute stream; the gather of super-chunk c is issued on a
+    side stream as soon as its slice is done, while the kernels of super-chunk c+1 run."""
+
+    def __init__(self, pairs: int, world: int, rank: int, chunks: int):
+        self.pairs, self.world, self.rank, self.chunks = pairs, world, rank, max(1, chunks)
+        self.sub = (pairs + world * self.chunks - 1) // (world * self.chunks)
+        self.total = self.sub * world * self.chunks
+
+    def slice_range(self, c: int, r: int | None = None) -> tuple[int, int]:
+        """packed range [lo, hi) of slice (c, r); empty past the end of the pair space"""
+        r = self.rank if r is None else r
+        lo = min(self.pairs, (c * self.world + r) * self.sub)
+        return lo, min(self.pairs, lo + self.sub)
+
+    def super_chunk(self, buffer, c: int):
+        return buffer[c * self.world * self.sub:(c + 1) * self.world * self.sub]
+
+    def my_slice(self, buffer, c: int):
+        o = (c * self.world + self.rank) * self.sub
+        return buffer[o:o + self.sub]

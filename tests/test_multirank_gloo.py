@@ -16,7 +16,7 @@ import os, sys
 sys.path.insert(0, sys.argv[1])
 import numpy as np, torch, torch.distributed as dist
 import sequencealigner_amd as sa
-from sequencealigner_amd.distributed import gather_packed, rank_range
+from sequencealigner_amd.distributed import ChunkedGather, gather_packed, rank_range
 from tests.oracle_binding import Oracle
 from tests.synth import make_protein_set
 
@@ -31,6 +31,18 @@ packed[rank * per: rank * per + (hi - lo)] = torch.from_numpy(o.align_range(stor
 gather_packed(dist, packed, rank, per)
 full = o.align(store, scoring, triangular=True, threads=2)
 assert np.array_equal(packed[:store.pairs].numpy(), full), f"rank {rank}: gathered vector differs"
+# bench.py's overlapped schedule: chunk-major / rank-minor slices, one in-place all-gather per super-chunk
+sched = ChunkedGather(store.pairs, world, rank, 3)
+buf = torch.zeros(sched.total, dtype=torch.int32)
+works = []
+for c in range(sched.chunks):
+    lo, hi = sched.slice_range(c)
+    if hi > lo:
+        sched.my_slice(buf, c)[:hi - lo] = torch.from_numpy(o.align_range(store, scoring, lo, hi - lo, threads=2))
+    works.append(dist.all_gather_into_tensor(sched.super_chunk(buf, c), sched.my_slice(buf, c).clone(), async_op=True))
+for w in works:
+    w.wait()
+assert np.array_equal(buf[:store.pairs].numpy(), full), f"rank {rank}: chunked gather differs"
 # work-balanced cut points (the general driver's rule) cover the index exactly once
 b = store.partition(world)
 assert b[0] == 0 and b[-1] == store.pairs
@@ -56,6 +68,23 @@ def test_two_rank_gloo_sharding(tmp_path, oracle, sa):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "MULTIRANK_OK 2" in res.stdout
+
+
+def test_chunked_schedule_covers_index_once():
+    from sequencealigner_amd.distributed import ChunkedGather
+    for pairs in (1, 7, 4950, 49_995_000):
+        for world in (1, 2, 8):
+            for chunks in (1, 3, 4):
+                seen = []
+                for c in range(chunks):
+                    for r in range(world):
+                        lo, hi = ChunkedGather(pairs, world, r, chunks).slice_range(c)
+                        seen.append((lo, hi))
+                pos = 0
+                for lo, hi in seen:  # chunk-major, rank-minor order == packed order
+                    assert lo == min(pairs, pos) and hi >= lo
+                    pos = hi if hi > lo else pos
+                assert pos == pairs
 
 
 def test_rank_ranges_cover_index_once():
