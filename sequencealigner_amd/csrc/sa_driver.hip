@@ -834,8 +834,11 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 				break;
 			}
 		}
-		/* general path: double-buffered batches of packed scores */
-		const int64_t batch = std::min<int64_t>(std::max<int64_t>(total, 1), BATCH_PAIRS);
+		/* general path: double-buffered batches of packed scores; a job that would fit one reference-size
+		 * batch is still cut in ~8 pieces so the device->host copy of a piece overlaps the next kernels */
+		int64_t batch = std::min<int64_t>(std::max<int64_t>(total, 1), BATCH_PAIRS);
+		if (out.matrix && total > ((int64_t)8 << 20))
+			batch = std::min<int64_t>(batch, std::max<int64_t>((total + 7) / 8, (int64_t)4 << 20));
 		for (int k = 0; k < 2; k++) {
 			SA_HIP_CHECK(hipMalloc(&d_buf[k], sizeof(int32_t) * (size_t)batch), goto out);
 		}

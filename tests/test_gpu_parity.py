@@ -171,3 +171,43 @@ def test_baseline_sizes_sampled(cfg_name, n, sa, oracle, torch_cuda):
         assert torch.equal(out, out2)
         sums = [int(out2[a:b].to(torch.int64).sum()) for a, b in zip(bounds, bounds[1:])]
         assert sum(sums) == int(got.astype(np.int64).sum())
+
+
+@pytest.mark.parametrize("cfg_name", ["cfg4", "cfg5"])
+def test_baseline_full_size_cfg4_cfg5(cfg_name, sa, oracle, torch_cuda):
+    """BASELINE.json configs 4 and 5 at their FULL sizes on one GPU (50 000 DNA x ~150 bp SW/NUC.4.4 = 1.25e9 pairs;
+    100 000 protein x ~120 aa NW with the -f 0.9 filter applied first = up to 5e9 pairs), result kept in HBM:
+    300k randomly sampled pairs + the last column against the oracle, and every score inside the bounds the
+    method allows (a property no sample needs)."""
+    torch = torch_cuda
+    seqs, cfg = make_config(cfg_name)
+    if cfg_name == "cfg5":  # `-f 0.9`: planted near-duplicates are dropped before alignment (host filter of the CLI)
+        from tests.host_binding import Host
+        amino = sa.Scoring.from_names("nw", "blosum62", gap_pen=4).lut
+        kept = Host().filter(seqs, amino, 0.9)
+        assert 0.85 * len(seqs) < len(kept) < 0.95 * len(seqs)
+        assert oracle.filter(sa.SequenceStore.from_sequences(kept[:3000]), 0.9).all()  # survivors are mutually dissimilar
+        seqs = kept
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    with sa.Context(store, scoring, 0) as ctx:
+        out = torch.empty(ctx.pairs, dtype=torch.int32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        step = 1 << 30  # the reference batches too (seqalign_cuda.c:136); any split must give the same vector
+        for a in range(0, ctx.pairs, step):
+            ctx.align_range(a, min(step, ctx.pairs - a), out.data_ptr() + 4 * a, stream)
+        torch.cuda.synchronize()
+        rng = np.random.default_rng(11)
+        idx = np.sort(rng.integers(0, ctx.pairs, 300_000))
+        j = store.num - 1
+        idx = np.concatenate([idx, np.arange(j * (j - 1) // 2, j * (j - 1) // 2 + j)])
+        got = out[torch.from_numpy(idx).cuda()].cpu().numpy()
+        assert np.array_equal(got, oracle.align_pairs(store, scoring, idx))
+        lens = store.meta[:, 1].astype(np.int64)
+        smax = int(scoring.sub.max())
+        lo, hi = int(out.min()), int(out.max())
+        if cfg["method"] == "sw":
+            assert lo >= 0 and hi <= smax * int(lens.max())
+        else:
+            g = -scoring.gap_pen
+            assert hi <= smax * int(lens.max()) and lo >= -g * 2 * int(lens.max()) + int(scoring.sub.min()) * int(lens.max())
