@@ -364,9 +364,20 @@ int32_t sa_host_filter(struct sa_host_store *s, float threshold, int threads)
 			}
 		}
 	}
+	for (int32_t r = 0; r < num; r++)
+		lost[r] = !lost[r]; /* -> keep mask */
+	const int32_t kept = sa_host_compact(s, lost);
+	free(lost);
+	return kept;
+}
+
+int32_t sa_host_compact(struct sa_host_store *s, const uint8_t *keep)
+{
+	struct sa_meta *meta = s->in.meta;
+	const int32_t num = s->in.num;
 	int32_t kept = 0, used = 0, mx = 0;
 	for (int32_t r = 0; r < num; r++) {
-		if (lost[r])
+		if (!keep[r])
 			continue;
 		struct sa_meta m = meta[r];
 		if (used != m.off)
@@ -376,7 +387,6 @@ int32_t sa_host_filter(struct sa_host_store *s, float threshold, int threads)
 		meta[kept++] = m;
 		mx = m.len > mx ? m.len : mx;
 	}
-	free(lost);
 	s->in.num = kept;
 	s->in.max = mx;
 	s->blob_bytes = (size_t)used;

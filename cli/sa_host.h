@@ -46,6 +46,10 @@ void sa_host_store_free(struct sa_host_store *s);
  * compacts blob + meta in place (filter.c:66-79).  Returns kept count (<0 on error). */
 int32_t sa_host_filter(struct sa_host_store *s, float threshold, int threads);
 
+/* Compacts blob + meta in place keeping the sequences with keep[k] != 0 (filter.c:66-79); returns the
+ * number kept (<0 when fewer than 2 remain). */
+int32_t sa_host_compact(struct sa_host_store *s, const uint8_t *keep);
+
 /* Result matrix: anonymous zero-filled mmap (os.c:32-141); bytes = 4*N*N or 4*N(N-1)/2. */
 int32_t *sa_host_matrix_alloc(size_t num, bool triangular);
 void sa_host_matrix_free(int32_t *m, size_t num, bool triangular);

@@ -346,9 +346,17 @@ int main(int argc, char **argv)
 	t_in = now() - t0;
 	t0 = now();
 	const int32_t before = store.in.num;
-	if (sa_host_filter(&store, o.filter, o.threads) < 0) {
-		err("%s", sa_host_error());
-		return 1;
+	if (o.filter > 0.0f) { /* similarity relation on the device, greedy keep/drop in sequence order (filter.c:14-89) */
+		uint8_t *keep = malloc((size_t)store.in.num);
+		if (!keep || sa_hip_filter(store.in, o.filter, keep) < 0) {
+			err("%s", keep ? sa_last_error() : "Out of memory during sequence filtering");
+			return 1;
+		}
+		if (sa_host_compact(&store, keep) < 0) {
+			err("%s", sa_host_error());
+			return 1;
+		}
+		free(keep);
 	}
 	t_filter = now() - t0;
 	if (o.filter > 0.0f)

@@ -99,6 +99,14 @@ bool sa_hip_memory(size_t bytes);
  * slice straight into out.matrix), or the first n with SA_HIP_DEVICES=n. */
 bool sa_hip_align(struct sa_input in, struct sa_output out, const struct sa_scoring *sc);
 
+/* Device-assisted replacement of `bool filter(struct input *)` (src/bio/filter.c:14-89, the `-f` option):
+ * keep[k] (in.num bytes) receives 1 for sequences that survive, 0 for dropped ones, with the reference's
+ * SEQUENTIAL semantics (for j ascending, j is dropped iff some kept i<j has
+ * matches(first min(len))/min(len) >= threshold in float).  The O(N^2 L) relation is computed on the device
+ * as a bit matrix, the order-dependent keep/drop on the host.  Returns the number kept, <0 on error.
+ * threshold <= 0 keeps everything (filter.c:16-17).  The caller compacts its store (filter.c:66-79). */
+int32_t sa_hip_filter(struct sa_input in, float threshold, uint8_t *keep);
+
 /* ---- device-resident layer (what sa_hip_align is built from) -------------
  * Used by multi-process drivers (one process per GPU + RCCL all-gather of the
  * packed slices, bench.py) and by callers that keep results in HBM. */

@@ -11,6 +11,7 @@ src/interface/seqalign_cuda.h) on top of the C ABI in include/seqalign_hip.h:
     -a/-m/-p/-s/-e parse+validate                Scoring.from_names   (bio/align.c:87-142, bio/matrices.c:44-58)
     bool cuda_memory(size_t)                     hip_memory(bytes)    (seqalign_cuda.h:7)
     bool cuda_align(struct input, struct output) hip_align(store, scoring, triangular)  (seqalign_cuda.h:9)
+    bool filter(struct input *)                  hip_filter(store, threshold)           (bio/filter.c:14)
     kernel(scores, start, batch)                 Context.align_range  (bio/align.h:48)
 
 All compute happens in libseqalign_hip.so (hand-written HIP for gfx950).  There is no
@@ -24,6 +25,7 @@ from .binding import (  # noqa: F401
     device_count,
     device_name,
     hip_align,
+    hip_filter,
     hip_memory,
     library_path,
     load_library,
@@ -33,6 +35,6 @@ from .binding import (  # noqa: F401
 )
 
 __all__ = [
-    "AlignError", "Context", "Scoring", "SequenceStore", "device_count", "device_name", "hip_align",
+    "AlignError", "Context", "Scoring", "SequenceStore", "device_count", "device_name", "hip_align", "hip_filter",
     "hip_memory", "library_path", "load_library", "matrix_names", "method_names", "pair_count",
 ]

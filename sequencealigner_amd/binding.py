@@ -45,7 +45,7 @@ class _Scoring(C.Structure):  # struct sa_scoring
 
 #: every symbol include/seqalign_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
-    "sa_hip_memory", "sa_hip_align", "sa_ctx_create", "sa_ctx_destroy", "sa_ctx_pairs", "sa_pairs_cells",
+    "sa_hip_memory", "sa_hip_align", "sa_hip_filter", "sa_ctx_create", "sa_ctx_destroy", "sa_ctx_pairs", "sa_pairs_cells",
     "sa_ctx_align_range", "sa_ctx_expand_full", "sa_pairs_partition", "sa_ctx_timing", "sa_ctx_timing_read",
     "sa_matrix_load", "sa_matrix_count", "sa_matrix_name", "sa_matrix_is_nucleotide", "sa_method_parse",
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
@@ -91,6 +91,8 @@ def load_library() -> C.CDLL:
     lib.sa_hip_memory.restype = C.c_bool
     lib.sa_hip_align.argtypes = [_Input, _Output, C.POINTER(_Scoring)]
     lib.sa_hip_align.restype = C.c_bool
+    lib.sa_hip_filter.argtypes = [_Input, C.c_float, C.c_void_p]
+    lib.sa_hip_filter.restype = C.c_int32
     lib.sa_ctx_create.argtypes = [C.c_int, _Input, C.POINTER(_Scoring)]
     lib.sa_ctx_create.restype = C.c_void_p
     lib.sa_ctx_destroy.argtypes = [C.c_void_p]
@@ -303,6 +305,16 @@ def hip_align(store: SequenceStore, scoring: Scoring, triangular: bool = False, 
     if matrix is None:
         return None
     return matrix if triangular else matrix.reshape(n, n)
+
+
+def hip_filter(store: SequenceStore, threshold: float) -> np.ndarray:
+    """`filter()` replacement (reference src/bio/filter.c:14-89): boolean keep mask with the sequential semantics
+    of `-f threshold`; the similarity relation is computed on the device."""
+    keep = np.ones(store.num, dtype=np.uint8)
+    rc = load_library().sa_hip_filter(store._as_c(), C.c_float(threshold), keep.ctypes.data)
+    if rc < 0:
+        raise AlignError(_err())
+    return keep.astype(bool)
 
 
 class Context:

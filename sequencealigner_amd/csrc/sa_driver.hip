@@ -768,6 +768,94 @@ extern "C" int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t 
 	return 0;
 }
 
+/* ---- sa_hip_filter: device-assisted similarity filter (reference src/bio/filter.c:14-89) ---- */
+extern "C" int32_t sa_hip_filter(struct sa_input in, float threshold, uint8_t *keep)
+{
+	if (!in.seqs || !in.meta || !keep || in.num < 1) {
+		sa_set_error("sa_hip_filter: bad arguments");
+		return -1;
+	}
+	const int32_t num = in.num;
+	for (int32_t k = 0; k < num; k++)
+		keep[k] = 1;
+	if (threshold <= 0.0f)
+		return num;
+	if (!device_ready(0))
+		return -1;
+	/* tight copy of the raw residues (the filter compares bytes, filter.c:49) */
+	std::vector<int32_t> off((size_t)num + 1, 0);
+	int64_t end = 0;
+	for (int32_t k = 0; k < num; k++) {
+		if (in.meta[k].len < 1 || in.meta[k].off < 0) {
+			sa_set_error("Sequence #%d has invalid offset/length", k + 1);
+			return -1;
+		}
+		off[(size_t)k] = (int32_t)end;
+		end += (int64_t)in.meta[k].len + 1;
+		if (end > INT32_MAX) {
+			sa_set_error("Sequence store exceeds 2 GiB");
+			return -1;
+		}
+	}
+	off[(size_t)num] = (int32_t)end;
+	std::vector<uint8_t> blob((size_t)end, 0);
+	for (int32_t k = 0; k < num; k++)
+		memcpy(blob.data() + off[(size_t)k], in.seqs + in.meta[k].off, (size_t)in.meta[k].len);
+
+	uint8_t *d_blob = nullptr;
+	int32_t *d_off = nullptr;
+	unsigned long long *d_rel = nullptr, *h_rel = nullptr;
+	int32_t kept = -1;
+	do {
+		SA_HIP_CHECK(hipMalloc(&d_blob, blob.size()), break);
+		SA_HIP_CHECK(hipMalloc(&d_off, sizeof(int32_t) * off.size()), break);
+		SA_HIP_CHECK(hipMemcpy(d_blob, blob.data(), blob.size(), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(d_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice), break);
+		/* bands of 64-row tiles, at most ~256 MiB of relation words in flight */
+		const int32_t tiles = (num + 63) / 64;
+		const long long budget_words = (256LL << 20) / 8;
+		const long long widest = (num + 63) / 64; /* words of the longest row */
+		int32_t band_tiles = (int32_t)std::max<long long>(1, budget_words / (64 * widest));
+		band_tiles = std::min(band_tiles, tiles);
+		const size_t band_words = (size_t)(64LL * band_tiles * widest);
+		SA_HIP_CHECK(hipMalloc(&d_rel, sizeof(unsigned long long) * band_words), break);
+		SA_HIP_CHECK(hipHostMalloc(&h_rel, sizeof(unsigned long long) * band_words), break);
+		std::vector<unsigned long long> keptbits((size_t)widest + 1, 0ULL);
+		keptbits[0] = 1ULL; /* sequence 0 is always kept */
+		bool failed = false;
+		for (int32_t jt0 = 0; jt0 < tiles && !failed; jt0 += band_tiles) {
+			const int32_t rows_t = std::min(band_tiles, tiles - jt0);
+			const long long j_lo = 64LL * jt0, j_hi = std::min<long long>(num, 64LL * (jt0 + rows_t));
+			const long long base = sa_filter_row_offset(j_lo), words = sa_filter_row_offset(j_hi) - base;
+			SA_HIP_CHECK(sa_launch_filter_relation(d_blob, d_off, num, threshold, d_rel, jt0, rows_t, nullptr), failed = true; break);
+			SA_HIP_CHECK(hipMemcpy(h_rel, d_rel, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost), failed = true; break);
+			/* greedy keep/drop in sequence order (filter.c:38-55 run with one thread) */
+			for (long long j = std::max<long long>(j_lo, 1); j < j_hi; j++) {
+				const unsigned long long *row = h_rel + (sa_filter_row_offset(j) - base);
+				const long long nw = (j + 63) / 64;
+				bool lost = false;
+				for (long long w = 0; w < nw && !lost; w++)
+					lost = (row[w] & keptbits[(size_t)w]) != 0;
+				if (lost)
+					keep[j] = 0;
+				else
+					keptbits[(size_t)(j / 64)] |= 1ULL << (j % 64);
+			}
+		}
+		if (failed)
+			break;
+		kept = 0;
+		for (int32_t k = 0; k < num; k++)
+			kept += keep[k];
+	} while (0);
+	(void)hipFree(d_blob);
+	(void)hipFree(d_off);
+	(void)hipFree(d_rel);
+	if (h_rel)
+		(void)hipHostFree(h_rel);
+	return kept;
+}
+
 /* ---- sa_hip_align: the cuda_align replacement (host buffers in, host matrix out) ---------- */
 
 namespace {

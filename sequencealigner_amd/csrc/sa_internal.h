@@ -89,6 +89,11 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workg
 hipError_t sa_launch_generic(int method, const SaGenericArgs &a, int blocks, hipStream_t s);
 const char *sa_generic_kernel_name(int method);
 
+/* similarity filter relation (sa_filter.hip) */
+long long sa_filter_row_offset(long long j);
+hipError_t sa_launch_filter_relation(const uint8_t *codes, const int32_t *off, int32_t num, float threshold,
+				      unsigned long long *rel, int32_t jt0, int32_t tile_rows, hipStream_t s);
+
 hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t num, hipStream_t s);
 
 #endif /* SA_INTERNAL_H */

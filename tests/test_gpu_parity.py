@@ -90,6 +90,25 @@ def test_multi_device_driver_path(sa, oracle, monkeypatch):
         monkeypatch.delenv("SA_HIP_SPLIT")
 
 
+def test_device_filter_matches_reference_semantics(sa, oracle):
+    """sa_hip_filter (relation on the device, greedy resolution on the host) == the reference's filter run with
+    one thread: golden keep list, oracle on planted near-duplicates, ragged lengths, thresholds 0 / 1."""
+    import json
+    from tests.golden_util import GOLDEN_DIR
+    from tests.synth import make_near_duplicates
+    z = np.load(GOLDEN_DIR / "filter_f0.9.npz")
+    meta = np.ascontiguousarray(z["meta"], np.int32)
+    store = sa.SequenceStore(blob=np.ascontiguousarray(z["blob"]), meta=meta, num=meta.shape[0], max=int(meta[:, 1].max()))
+    thr = json.loads(str(z["params"]))["threshold"]
+    assert list(np.nonzero(sa.hip_filter(store, thr))[0]) == list(z["kept"])
+    for n, lo, hi, dup, seed in ((700, 30, 60, 0.3, 9), (3000, 80, 400, 0.2, 10), (130, 1, 9, 0.5, 12)):
+        seqs = make_near_duplicates(make_protein_set(n, lo, hi, seed), dup, 0.05, seed)
+        st = sa.SequenceStore.from_sequences(seqs)
+        for t in (0.9, 0.5, 1.0):
+            assert np.array_equal(sa.hip_filter(st, t), oracle.filter(st, t)), (n, t)
+        assert sa.hip_filter(st, 0.0).all()
+
+
 def test_error_behaviour(sa):
     sc = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
     with pytest.raises(sa.AlignError, match="Not enough sequences"):
