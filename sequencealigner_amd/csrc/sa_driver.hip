@@ -892,6 +892,7 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 	int32_t *d_buf[2] = { nullptr, nullptr };
 	int32_t *d_full = nullptr;
 	int32_t *h_stage[2] = { nullptr, nullptr };
+	int32_t *pinned_dst = nullptr;
 	hipStream_t compute = nullptr, copy = nullptr;
 	hipEvent_t done[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
 	const int64_t total = hi - lo;
@@ -915,6 +916,12 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 					break;
 				if (sa_ctx_expand_full(ctx, d_buf[0], d_full, compute))
 					break;
+				if (!getenv("SA_HIP_NO_PIN")) { /* page-lock the destination while the kernels run */
+					if (hipHostRegister(out.matrix, sizeof(int32_t) * dim * dim, hipHostRegisterDefault) == hipSuccess)
+						pinned_dst = out.matrix;
+					else
+						(void)hipGetLastError();
+				}
 				SA_HIP_CHECK(hipMemcpyAsync(out.matrix, d_full, sizeof(int32_t) * dim * dim,
 							    hipMemcpyDeviceToHost, compute), break);
 				SA_HIP_CHECK(hipStreamSynchronize(compute), break);
@@ -934,6 +941,15 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 			for (int k = 0; k < 2; k++) {
 				SA_HIP_CHECK(hipHostMalloc(&h_stage[k], sizeof(int32_t) * (size_t)batch), goto out);
 			}
+		}
+		/* triangular destination: page-lock the caller's slice for the duration of the call so the copies
+		 * are true DMA and overlap the kernels (a pageable destination is staged and serialises).  Best
+		 * effort: if registration fails the copies still work, only slower. */
+		if (out.matrix && out.triangular && total > 0 && !getenv("SA_HIP_NO_PIN")) {
+			if (hipHostRegister(out.matrix + lo, sizeof(int32_t) * (size_t)total, hipHostRegisterDefault) == hipSuccess)
+				pinned_dst = out.matrix + lo;
+			else
+				(void)hipGetLastError();
 		}
 		{
 			int64_t issued = 0, delivered = 0;
@@ -1003,6 +1019,8 @@ out:
 		if (copied[k])
 			(void)hipEventDestroy(copied[k]);
 	}
+	if (pinned_dst)
+		(void)hipHostUnregister(pinned_dst);
 	if (d_full)
 		(void)hipFree(d_full);
 	if (compute)
