@@ -1,0 +1,84 @@
+"""GPU (-m gpu): randomized parity sweep of the fast path's corner cases against the oracle: every column-length
+class boundary (n = W-1, W, W+1), streams of length-1 sequences, all methods, random matrices and gap values up to
+the s8-profile limit and beyond (generic fallback), packed sub-ranges that cut columns, and every stream length the
+planner can choose.  Seeds are fixed: the case list is identical on every run."""
+import numpy as np
+import pytest
+
+from tests.synth import AMINO20, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+W_CLASSES = [64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 896, 1024]
+
+
+def rand_seqs(rng, n, lens, alphabet):
+    a = np.frombuffer(alphabet, np.uint8)
+    return [a[rng.integers(0, len(a), int(l))].tobytes() for l in lens]
+
+
+def check(sa, oracle, seqs, scoring, sub=None):
+    store = sa.SequenceStore.from_sequences(seqs)
+    want = oracle.align(store, scoring, triangular=True)
+    got = sa.hip_align(store, scoring, triangular=True)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, f"{bad.size} mismatches, first at packed index {bad[:5]}: got {got[bad[:5]]} want {want[bad[:5]]}"
+
+
+@pytest.mark.parametrize("method", ["nw", "ga", "sw"])
+def test_class_boundaries(method, sa, oracle):
+    """column sequences of length W-1, W, W+1 for every class, mixed with short and long row sequences"""
+    rng = np.random.default_rng(100)
+    gaps = dict(gap_pen=4) if method == "nw" else dict(gap_open=10, gap_extend=1)
+    scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+    for w in W_CLASSES:
+        lens = [1, 2, 3, w - 1, w, w + 1, 17, w // 2, w, 5, w - 1, 1, w + 1, 33]
+        check(sa, oracle, rand_seqs(rng, len(lens), lens, AMINO20), scoring)
+
+
+def test_random_parameter_sweep(sa, oracle):
+    rng = np.random.default_rng(101)
+    matrices = ["blosum62", "blosum45", "blosum100", "pam30", "pam250", "pam500", "blosum30"]
+    for case in range(60):
+        method = ["nw", "ga", "sw"][case % 3]
+        matrix = matrices[int(rng.integers(0, len(matrices)))]
+        if method == "nw":
+            gaps = dict(gap_pen=int(rng.choice([0, 1, 2, 4, 7, 11, 20, 40, 55, 300])))
+        else:
+            o, e = int(rng.choice([0, 1, 3, 5, 10, 12, 25, 50, 200])), int(rng.choice([0, 1, 2, 3, 5, 10, 30]))
+            gaps = dict(gap_open=o, gap_extend=e)
+        regime = case % 4
+        n = int(rng.integers(40, 160))
+        if regime == 0:
+            lens = rng.integers(1, 12, n)          # very short: many terminators in flight
+        elif regime == 1:
+            lens = rng.integers(50, 140, n)        # the benchmark regime
+        elif regime == 2:
+            lens = rng.integers(1, 400, n)         # ragged, several classes in one job
+        else:
+            lens = np.where(rng.random(n) < 0.1, rng.integers(600, 1300, n), rng.integers(20, 90, n))  # a few > 1024
+        scoring = sa.Scoring.from_names(method, matrix, **gaps)
+        try:
+            check(sa, oracle, rand_seqs(rng, n, lens, AMINO20), scoring)
+        except AssertionError as exc:
+            raise AssertionError(f"case {case}: {method} {matrix} {gaps} regime {regime}: {exc}") from None
+
+
+def test_subranges_and_stream_lengths(sa, oracle, torch_cuda=None):
+    """any packed sub-range, however it cuts columns and whatever stream length the planner picks for it"""
+    import torch
+    rng = np.random.default_rng(102)
+    seqs = rand_seqs(rng, 700, rng.integers(60, 130, 700), AMINO20)
+    store = sa.SequenceStore.from_sequences(seqs)
+    for method, gaps in (("nw", dict(gap_pen=4)), ("ga", dict(gap_open=10, gap_extend=1)), ("sw", dict(gap_open=10, gap_extend=1))):
+        scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+        want = oracle.align(store, scoring, triangular=True)
+        with sa.Context(store, scoring, 0) as ctx:
+            stream = torch.cuda.current_stream().cuda_stream
+            for _ in range(12):
+                a = int(rng.integers(0, ctx.pairs - 1))
+                b = int(min(ctx.pairs, a + rng.integers(1, 60_000)))
+                out = torch.full((b - a,), -12345, dtype=torch.int32, device="cuda")
+                ctx.align_range(a, b - a, out.data_ptr(), stream)
+                torch.cuda.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want[a:b]), (method, a, b)
