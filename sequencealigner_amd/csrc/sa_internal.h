@@ -49,10 +49,11 @@ struct SaGenericArgs {
 #endif
 /* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K */
 #define SA_SYS_CLASS_LIST(X)                                                                        \
-	X(0, 16, 4) X(1, 16, 5) X(2, 16, 6) X(3, 16, 7) X(4, 16, 8)                                 \
-	X(5, 32, 5) X(6, 32, 6) X(7, 32, 7) X(8, 32, 8)                                             \
-	X(9, 64, 5) X(10, 64, 6) X(11, 64, 7) X(12, 64, 8)                                          \
-	X(13, 64, 10) X(14, 64, 12) X(15, 64, 14) X(16, 64, 16)
+	X(0, 16, 1) X(1, 16, 2) X(2, 16, 3)                                                         \
+	X(3, 16, 4) X(4, 16, 5) X(5, 16, 6) X(6, 16, 7) X(7, 16, 8)                                 \
+	X(8, 32, 5) X(9, 32, 6) X(10, 32, 7) X(11, 32, 8)                                           \
+	X(12, 64, 5) X(13, 64, 6) X(14, 64, 7) X(15, 64, 8)                                         \
+	X(16, 64, 10) X(17, 64, 12) X(18, 64, 14) X(19, 64, 16)
 struct SaSysClass {
 	int G, K;
 };

@@ -9,7 +9,7 @@ from tests.synth import AMINO20, splitmix64
 
 pytestmark = pytest.mark.gpu
 
-W_CLASSES = [64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 896, 1024]
+W_CLASSES = [16, 32, 48, 64, 80, 96, 112, 128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 896, 1024]
 
 
 def rand_seqs(rng, n, lens, alphabet):
