@@ -34,7 +34,10 @@ struct sa_ctx {
 	int32_t *d_scratch = nullptr;
 	int64_t scratch_stride = 0;
 	int generic_blocks = 0;
-	unsigned *d_counters = nullptr; /* one tile counter per systolic class launch */
+	unsigned *d_counters = nullptr; /* one tile counter per systolic class launch (+1: strip-mined launch) */
+	int32_t *d_long_scratch = nullptr; /* strip boundaries of the strip-mined launch, per workgroup   */
+	int64_t long_stride = 0;           /* ints per workgroup                                          */
+	int long_wgs = 0;
 	int persistent_wgs = 0;         /* workgroups of a persistent systolic launch  */
 	/* the class launches of one range run concurrently on side streams (their tails overlap) */
 	enum { NSIDE = 4 };
@@ -255,7 +258,8 @@ static void systolic_setup(sa_ctx *ctx)
 	}
 	if (pmax > 127 || smin + pconst < -127)
 		return;
-	const int64_t wmax = (int64_t)SA_SYS_CLASSES[SA_SYS_NCLASSES - 1].G * SA_SYS_CLASSES[SA_SYS_NCLASSES - 1].K;
+	/* widest column the fast path will see: padded to whole strips when longer than the widest class */
+	const int64_t wmax = ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W;
 	if ((gain * wmax + slack) * (SA_SYS_CHUNK + 2) >= ((int64_t)1 << 29))
 		return;
 	ctx->sys_ok = true;
@@ -265,13 +269,14 @@ static void systolic_setup(sa_ctx *ctx)
 	ctx->sys_slack = slack;
 }
 
-/* smallest kernel class whose column budget W = G*K holds a column sequence of length n; -1 if none */
+/* smallest kernel class whose column budget W = G*K holds a column sequence of length n; longer columns go
+ * to the strip-mined launch of the widest class */
 static int systolic_class_for(int32_t n)
 {
 	for (int c = 0; c < SA_SYS_NCLASSES; c++)
 		if (SA_SYS_CLASSES[c].G * SA_SYS_CLASSES[c].K >= n)
 			return c;
-	return -1;
+	return SA_SYS_CLASS_LONG;
 }
 
 extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa_scoring *sc)
@@ -326,7 +331,7 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		blocks = std::max<int64_t>(prop.multiProcessorCount, std::min(blocks, budget / per_block));
 		ctx->generic_blocks = (int)blocks;
 		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
-		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * SA_SYS_NCLASSES), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * (SA_SYS_NCLASSES + 1)), break);
 		ctx->persistent_wgs = prop.multiProcessorCount * 32;
 		bool streams_ok = true;
 		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming), streams_ok = false);
@@ -364,6 +369,7 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 	(void)hipFree(ctx->d_sub8);
 	(void)hipFree(ctx->d_scratch);
 	(void)hipFree(ctx->d_counters);
+	(void)hipFree(ctx->d_long_scratch);
 	for (int k = 0; k < sa_ctx::NSIDE; k++) {
 		if (ctx->side[k])
 			(void)hipStreamDestroy(ctx->side[k]);
@@ -539,8 +545,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 	}
 	ctx->plan = nullptr;
 	const int64_t end = start + count;
-	std::vector<std::vector<int32_t>> jl((size_t)SA_SYS_NCLASSES), tp((size_t)SA_SYS_NCLASSES);
-	std::vector<int64_t> cpairs((size_t)SA_SYS_NCLASSES, 0), ccells((size_t)SA_SYS_NCLASSES, 0);
+	std::vector<std::vector<int32_t>> jl((size_t)SA_SYS_NCLASSES + 1), tp((size_t)SA_SYS_NCLASSES + 1);
+	std::vector<int64_t> cpairs((size_t)SA_SYS_NCLASSES + 1, 0), ccells((size_t)SA_SYS_NCLASSES + 1, 0);
 	std::vector<int64_t> lenpre((size_t)ctx->num + 1, 0);
 	for (int32_t k = 0; k < ctx->num; k++)
 		lenpre[(size_t)k + 1] = lenpre[(size_t)k] + ctx->meta[(size_t)k].len;
@@ -570,7 +576,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 				plan.generic.emplace_back(tri + ia, ib - ia);
 			continue;
 		}
-		const int rows = (64 / SA_SYS_CLASSES[cls].G) * plan.chunk;
+		/* strip-mined tiles stream one group of at most 16 sequences (their scratch lines are per position) */
+		const int rows = cls == SA_SYS_CLASS_LONG ? std::min(plan.chunk, 16) : (64 / SA_SYS_CLASSES[cls].G) * plan.chunk;
 		if (tp[(size_t)cls].empty())
 			tp[(size_t)cls].push_back(0);
 		const int64_t tiles = (ib - ia + rows - 1) / rows;
@@ -584,7 +591,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		ccells[(size_t)cls] += (int64_t)n * (lenpre[(size_t)ib] - lenpre[(size_t)ia]);
 	}
 	bool ok = true;
-	for (int cls = 0; cls < SA_SYS_NCLASSES && ok; cls++) {
+	for (int cls = 0; cls <= SA_SYS_NCLASSES && ok; cls++) {
 		if (jl[(size_t)cls].empty())
 			continue;
 		sa_ctx::ClassLaunch cl;
@@ -655,7 +662,7 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 	 * launches go to side streams forked from / joined back into the caller's stream so they run concurrently */
 	const bool fan_out = ctx->plan->classes.size() > 1 && !getenv("SA_HIP_SERIAL_CLASSES");
 	if (!ctx->plan->classes.empty()) {
-		SA_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * SA_SYS_NCLASSES, s), return 1);
+		SA_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * (SA_SYS_NCLASSES + 1), s), return 1);
 	}
 	if (fan_out) {
 		SA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s), return 1);
@@ -668,7 +675,9 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 			s = ctx->side[side_k];
 			SA_HIP_CHECK(hipStreamWaitEvent(s, ctx->fork_ev, 0), return 1);
 		}
-		const int W = SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
+		const bool is_long = cl.cls == SA_SYS_CLASS_LONG;
+		const int64_t W = is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
+					  : SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
 		SaSysArgs a{};
 		a.codes = ctx->d_codes;
 		a.off = ctx->d_off;
@@ -687,10 +696,25 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.gap_e = ctx->sc.gap_ext;
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
 		a.counter = ctx->d_counters + cl.cls;
-		a.chunk = ctx->plan->chunk;
+		a.chunk = is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
+		if (is_long) {
+			/* scratch: two lines (V and X) of one tile's longest possible row stream per workgroup,
+			 * as many workgroups as fit a 4 GiB budget */
+			if (!ctx->d_long_scratch) {
+				ctx->long_stride = 2 * (16 * ((int64_t)ctx->max_len + 1) + 64);
+				const int64_t budget_ints = ((int64_t)4 << 30) / 4;
+				ctx->long_wgs = (int)std::max<int64_t>(64, std::min<int64_t>(ctx->persistent_wgs / 4, budget_ints / ctx->long_stride));
+				SA_HIP_CHECK(hipMalloc(&ctx->d_long_scratch, sizeof(int32_t) * (size_t)(ctx->long_stride * ctx->long_wgs)), return 1);
+			}
+			a.long_scratch = ctx->d_long_scratch;
+			a.long_stride = ctx->long_stride;
+		}
 		char name[64];
-		snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
-			 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
+		if (is_long)
+			snprintf(name, sizeof(name), "sa_k_systolic<%s,G64,K16,strips>", METHOD_TAG[ctx->sc.method]);
+		else
+			snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
+				 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
 		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
 		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
 		unsigned long long *d_stamps = nullptr;
@@ -701,7 +725,8 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
-		const int wgs = (int)std::min<int64_t>(ctx->persistent_wgs, (cl.ntiles + SA_SYS_WPB - 1) / SA_SYS_WPB);
+		const int wgs = (int)std::min<int64_t>(is_long ? ctx->long_wgs : ctx->persistent_wgs,
+						       (cl.ntiles + SA_SYS_WPB - 1) / SA_SYS_WPB);
 		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
 		if (d_stamps) {
 			std::vector<unsigned long long> h(3 * (size_t)cl.ntiles);

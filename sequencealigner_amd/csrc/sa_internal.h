@@ -62,7 +62,9 @@ static const SaSysClass SA_SYS_CLASSES[] = {
 	SA_SYS_CLASS_LIST(SA_SYS_ENTRY)
 #undef SA_SYS_ENTRY
 };
-enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLASSES[0])) };
+enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLASSES[0])),
+	     SA_SYS_CLASS_LONG = SA_SYS_NCLASSES, /* strip-mined launch of the widest class (G=64, K=16) */
+	     SA_SYS_LONG_W = 1024 };
 
 struct SaSysArgs {
 	const uint8_t *codes;    /* encoded store, tight layout: sequence k at off[k], terminator after it */
@@ -78,6 +80,8 @@ struct SaSysArgs {
 	int32_t gap_g, gap_o, gap_e;
 	int32_t delta;           /* baseline raise per sequence                                           */
 	int32_t chunk;           /* sequences per group stream of a wave-tile, 1..SA_SYS_CHUNK            */
+	int32_t *long_scratch;   /* strip-mined launch: per workgroup 2 lines of long_stride/2 ints       */
+	int64_t long_stride;     /* ints per workgroup (>= 2 * longest row stream of a tile)              */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */

@@ -99,10 +99,15 @@ __device__ __forceinline__ int slot_byte(const uint4 &w, int q)
 	return (int)(int8_t)(v >> (8 * (q & 3)));
 }
 
-/* one wave-tile: column j = A.jlist[..] against 64/G streams of up to 64 row sequences */
-template <int METHOD, int G, int K>
+/* one wave-tile: column j = A.jlist[..] against 64/G streams of up to 64 row sequences.
+ * LONG (G = 64, K = 16 only): column sequences longer than W = 1024 are processed in ceil(n/W) strips of W
+ * columns, one full pass over the row stream per strip.  The strip's last column (and, for the affine
+ * methods, the X value leaving it) is parked per row in an HBM scratch line of the workgroup and becomes
+ * the first lane's injected boundary of the next strip -- the same role the baseline plays in strip 0. */
+template <int METHOD, int G, int K, bool LONG>
 __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t t_raw, const int32_t ntiles)
 {
+	static_assert(!LONG || (G == 64 && K == 16), "strip mining is instantiated for the widest class only");
 	constexpr int WPB = SA_SYS_WPB; /* waves per workgroup, each wave owns one wave-tile and its own LDS */
 	constexpr int NG = 64 / G;
 	constexpr int W = G * K;
@@ -122,7 +127,8 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	__shared__ __attribute__((aligned(16))) uint8_t s_prof_all[WPB * PROF_BYTES];
 	/* s_out (scores leaving the pipeline) is only written after the profile build, which is the only
 	 * reader of the staged substitution matrix: they share storage */
-	constexpr int OUT_INTS = NG * CH * 4 > SA_SUB_DIM * SA_SUB_DIM ? NG * CH : SA_SUB_DIM * SA_SUB_DIM / 4;
+	constexpr int OUT_INTS = (NG * CH * 4 > SA_SUB_DIM * SA_SUB_DIM ? NG * CH : SA_SUB_DIM * SA_SUB_DIM / 4) +
+				 (LONG ? SA_SUB_DIM * SA_SUB_DIM / 4 : 0); /* LONG: the matrix keeps its own words */
 	__shared__ int32_t s_out_all[WPB * OUT_INTS];
 	/* token ring per lane group: RING stream positions as u16.  Stored twice (index i and i+RING) so a
 	 * run of 16 consecutive positions never wraps, and in two copies skewed by one position so that
@@ -141,7 +147,7 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	const int wv = threadIdx.x >> 6;
 	uint8_t *s_prof = s_prof_all + wv * PROF_BYTES;
 	int32_t *s_out = s_out_all + wv * OUT_INTS;
-	int8_t *s_sub = reinterpret_cast<int8_t *>(s_out);
+	int8_t *s_sub = reinterpret_cast<int8_t *>(LONG ? s_out + NG * CH : s_out);
 	uint16_t *s_ring = s_ring_all + wv * (NG * GSTRIDE);
 	const int lig = lane & (G - 1);
 	const int grp = lane / G;
@@ -168,284 +174,326 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	const int32_t i_count = (int32_t)ib64 - i_begin < NG * ch ? (int32_t)ib64 - i_begin : NG * ch;
 	const int32_t offj = A.off[j];
 	const int32_t n = A.off[j + 1] - offj - 1;
+	/* column slots: nstrips*W of them, the sequence right-aligned (padding only left of column 1) */
+	const int32_t nstrips = LONG ? (n + W - 1) / W : 1;
+	const int32_t pad = nstrips * W - n;
+	/* LONG: per-workgroup scratch lines holding, per stream position, what leaves a strip's last column */
+	int32_t *const vb = LONG ? A.long_scratch + (size_t)blockIdx.x * (size_t)A.long_stride : nullptr;
+	int32_t *const xb = LONG ? vb + (A.long_stride >> 1) : nullptr;
 
 	for (int k = lane; k < SA_SUB_DIM * SA_SUB_DIM; k += 64)
 		s_sub[k] = A.sub8[k];
 	__syncthreads();
 
-	/* ---- query profile of column sequence j for this lane's K column slots ---- */
-	{
-		int bq[K];
-#pragma unroll
-		for (int q = 0; q < K; q++) {
-			const int c0 = lig * K + q - (W - n);
-			bq[q] = c0 >= 0 ? (int)A.codes[offj + c0] : -1;
-		}
-		/* lanes holding the same columns split the table rows between them */
-		constexpr int SHARE = NT == 2 ? 1 : 64 / NSLOT;          /* builders per slot: 4, 2 or 1 */
-		constexpr int ROWS_EACH = (SA_CODE_ROWS + SHARE - 1) / SHARE;
-		const int slot = lane & (NSLOT - 1);
-		const int a_lo = NT == 2 ? 0 : (lane / NSLOT) * ROWS_EACH;
-		const int a_hi = NT == 2 ? SA_CODE_ROWS : (a_lo + ROWS_EACH < SA_CODE_ROWS ? a_lo + ROWS_EACH : SA_CODE_ROWS);
-		uint8_t *tbl = s_prof + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0);
-		for (int a = a_lo; a < a_hi; a++) {
-			uint32_t w[RB / 4];
-#pragma unroll
-			for (int k = 0; k < RB / 4; k++)
-				w[k] = 0x80808080u;
-#pragma unroll
-			for (int q = 0; q < K; q++) {
-				int v = -128;
-				if (a < SA_SUB_DIM && bq[q] >= 0) {
-					v = (int)s_sub[a * SA_SUB_DIM + bq[q]] + A.pconst;
-					/* Gotoh: the first real column sits right of a padding column whose N is
-					 * one q too low (see header): compensate in its diagonal term */
-					if (METHOD == SA_METHOD_GA && W != n && lig * K + q == W - n)
-						v -= A.q;
-				}
-				w[q >> 2] = (w[q >> 2] & ~(0xffu << (8 * (q & 3)))) | ((uint32_t)(v & 0xff) << (8 * (q & 3)));
-			}
-			uint32_t *dst = reinterpret_cast<uint32_t *>(tbl + a * ROWSTRIDE + slot * RB);
-#pragma unroll
-			for (int k = 0; k < RB / 4; k++)
-				dst[k] = w[k];
-		}
-	}
-	__syncthreads();
-
-	/* ---- row streams: group g streams sequences [ib_g, ib_g + cnt_g) ---- */
-	const int32_t ib_g = i_begin + grp * ch;
-	int32_t cnt_g = i_count - grp * ch;
-	cnt_g = cnt_g < 0 ? 0 : cnt_g > ch ? ch : cnt_g;
-	const int32_t sbeg = A.off[ib_g < A.num ? ib_g : 0];
-	const int32_t slen = cnt_g > 0 ? A.off[ib_g + cnt_g] - sbeg : 0;
-	int32_t smax = 0; /* longest stream of the wave */
-#pragma unroll
-	for (int g = 0; g < NG; g++) {
-		int32_t c = i_count - g * ch;
-		c = c < 0 ? 0 : c > ch ? ch : c;
-		const int32_t b = i_begin + g * ch;
-		const int32_t l = c > 0 ? A.off[b + c] - A.off[b] : 0;
-		smax = l > smax ? l : smax;
-	}
-	const int32_t steps = smax + G - 1;
-	const int32_t nblk = (steps + 15) >> 4;
-	const uint8_t *stream = A.codes + sbeg;
-	/* token prefetch: 16 stream bytes per DPP row and block, fetched two blocks ahead of their use.
-	 * The load is unconditional (clamped address); the out-of-stream select happens when the block is
-	 * converted, so the vmcnt wait lands a full block after the issue. */
-	const int32_t last = slen > 0 ? slen - 1 : 0;
-	const int r16 = lane & 15;
-	auto load_block = [&](int32_t blk) -> int {
-		const int32_t pos = (blk << 4) + r16;
-		return (int)stream[pos < last ? pos : last];
-	};
-	constexpr uint32_t SEPWORD = (uint32_t)SA_CODE_SEP << SH;
-	constexpr uint32_t NOPWORD = (uint32_t)SA_CODE_NOP << SH;
-	auto block_word = [&](int32_t blk, int raw) -> uint32_t { /* token -> profile row address */
-		const int32_t pos = (blk << 4) + r16;
-		return pos < slen ? (uint32_t)raw << SH : NOPWORD;
-	};
-	/* every DPP row writes the ring of the group it belongs to; only the group's first row carries
-	 * the stream (rows 1.. of a 32/64-lane group write a private scratch half that is never read) */
-	uint16_t *ring = s_ring + grp * GSTRIDE; /* copy 0 at [0, 2*RING), copy 1 at [COPY1, COPY1 + 2*RING) */
-	const bool feeder = (lane & (G - 1)) < 16;
-	auto ring_write = [&](int32_t blk, uint32_t word) {
-		if (feeder) {
-			const int p = (blk << 4) + r16;
-			const int i0 = p & (RING - 1), i1 = (p + 1) & (RING - 1);
-			ring[i0] = (uint16_t)word;
-			ring[i0 + RING] = (uint16_t)word;
-			ring[COPY1 + i1] = (uint16_t)word;
-			ring[COPY1 + i1 + RING] = (uint16_t)word;
-		}
-	};
-	/* terminator positions of a block of tokens: wave ballot (bit = lane) */
-	auto sep_ballot = [&](uint32_t word) -> unsigned long long { return __ballot(feeder && word == SEPWORD); };
-	/* any group: wave-uniform 16-bit mask of the block's terminator positions */
-	auto fold16 = [&](unsigned long long m) -> uint32_t {
-		m |= m >> 32;
-		m |= m >> 16;
-		return (uint32_t)m & 0xffffu;
-	};
-
 	const uint32_t slot_off = (uint32_t)((lane & (NSLOT - 1)) * RB + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0));
 	const int32_t delta = A.delta;
 	const int32_t gq = A.q, go = A.gap_o, ge = A.gap_e;
-
-	/* ---- DP state ---- */
-	int V[K];        /* NW: H'   GA: N     SW: No                               */
-	int Y[K];        /* GA: Y'   SW: Y                                          */
-	int vprev;       /* value of the column left of V[0], previous row (diag)   */
-	int xout;        /* GA/SW: X of the column right of V[K-1], current row     */
-	int fl = 0;      /* SW: floor of the row this lane is processing (travels with the row) */
-	int best = 0, carry = NEG;
-	int nsep = 0;
-	/* boundary value the group's first lane injects on an ordinary row of the FIRST sequence:
-	 * NW  B,  GA  B + 2q,  SW  B + o  (B = 0); a terminator row injects cspecial more (GA: B' + q) */
-	const int inj0 = METHOD == SA_METHOD_NW ? 0 : METHOD == SA_METHOD_GA ? 2 * gq : go;
-	const int cspecial = METHOD == SA_METHOD_GA ? -gq : 0;
-	if (METHOD == SA_METHOD_NW) {
-		vprev = 0;
-		xout = 0;
-#pragma unroll
-		for (int q = 0; q < K; q++)
-			V[q] = 0, Y[q] = 0;
-	} else if (METHOD == SA_METHOD_GA) {
-		vprev = leader ? gq : 2 * gq;
-		xout = gq;
-#pragma unroll
-		for (int q = 0; q < K; q++)
-			V[q] = 2 * gq, Y[q] = 2 * gq;
-	} else {
-		vprev = go;
-		xout = go;
-#pragma unroll
-		for (int q = 0; q < K; q++)
-			V[q] = go, Y[q] = go;
-	}
-
-	/* Injection vector of a block: feeder lane k holds the boundary value of the row at stream
-	 * position 16*blk + k, i.e. inj0 + DELTA * (terminators at positions <= that one) (+ cspecial on
-	 * the terminator row itself).  The group's first lane picks entry s at step s with a constant
-	 * row_shl:s DPP, so baseline raises need no branch and no per-step state. */
-	int seps_before = 0; /* terminators of this lane's row-stream in earlier blocks */
-	auto inject_vector = [&](unsigned long long m, uint32_t word) -> int {
-		const uint32_t half = (lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
-		const uint32_t seg = (lane & 16) ? half >> 16 : half & 0xffffu;
-		const int incl = __builtin_popcount(seg & ((2u << r16) - 1u));
-		const int v = inj0 + delta * (seps_before + incl) + (word == SEPWORD ? cspecial : 0);
-		seps_before += __builtin_popcount(seg);
-		return v;
-	};
-
-	/* the 16 tokens a lane meets in block blk: stream positions 16*blk - lig + s, two per dword */
-	auto ring_run = [&](int32_t blk, uint32_t (&two)[8]) {
-		const int phase = lig & 1;
-		const uint32_t *rp = reinterpret_cast<const uint32_t *>(
-			ring + phase * COPY1 + (((blk << 4) - lig + phase) & (RING - 1)));
-#pragma unroll
-		for (int k = 0; k < 8; k++)
-			two[k] = rp[k];
-	};
-	auto tok_of = [&](const uint32_t (&two)[8], int s) -> uint32_t {
-		return (s & 1) ? two[s >> 1] >> 16 : two[s >> 1] & 0xffffu;
-	};
-	auto prof_row = [&](uint32_t word) -> slot_t {
-		return *reinterpret_cast<const slot_t *>(s_prof + (word | slot_off));
-	};
-
-	/* ---- prologue: empty ring, block 0 in the ring, block 1 in flight ---- */
-	for (int k = lane; k < NG * GSTRIDE; k += 64)
-		s_ring[k] = (uint16_t)NOPWORD;
-	__syncthreads();
-	/* terminator bits seen by the LAST lane of a group: position p reaches it G-1 steps late.
-	 * hi bit k = position t0+k (current block), lo bit 64-d = position t0-d */
-	unsigned long long ev_lo = 0, ev_hi;
-	int injvec;
-	{
-		const uint32_t w0 = block_word(0, load_block(0));
-		ring_write(0, w0);
-		const unsigned long long m0 = sep_ballot(w0);
-		ev_hi = fold16(m0);
-		injvec = inject_vector(m0, w0);
-	}
-	int raw_next = load_block(1);
-	__syncthreads();
-	uint32_t w2[8]; /* current block's tokens */
-	ring_run(0, w2);
-	constexpr int PD = 4; /* profile rows are requested PD steps ahead of their use */
-	slot_t pq[PD];
-#pragma unroll
-	for (int s = 0; s < PD; s++)
-		pq[s] = prof_row(tok_of(w2, s));
-
-	unsigned long long st_c = 0, st_r = 0;
-	if (A.stamps) {
-		st_c = __builtin_amdgcn_s_memtime();
-		st_r = __builtin_amdgcn_s_memrealtime();
-	}
-	for (int32_t blk = 0; blk < nblk; blk++) {
-		/* steps of this block at which the last lane of some group meets a terminator */
-		const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1))) & 0xffffu);
-		/* next block's tokens go into the ring while this block computes */
-		const uint32_t wn = block_word(blk + 1, raw_next);
-		ring_write(blk + 1, wn);
-		const unsigned long long mn = sep_ballot(wn);
-		const int injvec_next = inject_vector(mn, wn);
-		raw_next = load_block(blk + 2);
-		uint32_t w2n[8]; /* next block's tokens, fetched mid-block so no LDS latency is exposed at the seam */
-
-#pragma unroll
-		for (int s = 0; s < 16; s++) {
-			const slot_t pw = pq[s % PD];
-			if (s == 6)
-				ring_run(blk + 1, w2n);
-			pq[s % PD] = prof_row(s + PD < 16 ? tok_of(w2, s + PD) : tok_of(w2n, s + PD - 16));
-			/* boundary value of this row for the group's first lane */
-			const int inj = dpp_row_shl(injvec, s);
-			if (METHOD == SA_METHOD_SW) {
-				carry = imax(shift_in<G>(NEG, carry, leader), best);
-			}
-			if (__builtin_expect((ev >> s) & 1u, 0)) { /* wave-uniform, rare: a score leaves the pipeline */
-				/* the empty volatile statement keeps this a scalar branch (s_bitcmp + s_cbranch_scc):
-				 * without it the uniform test is folded into the per-lane one and every step pays
-				 * v_cmp + s_and_saveexec + s_cbranch_execz (measured: +200 cycles per step and wave) */
-				asm volatile("" ::: "memory");
-				if (lig == G - 1 && tok_of(w2, s) == SEPWORD) {
-					s_out[grp * CH + nsep] = METHOD == SA_METHOD_SW ? carry : V[K - 1];
-					nsep++;
-				}
-			}
-			const int vleft = shift_in<G>(inj, V[K - 1], leader);
-			int d[K];
-			d[0] = vprev + slot_byte(pw, 0);
-#pragma unroll
-			for (int q = 1; q < K; q++)
-				d[q] = V[q - 1] + slot_byte(pw, q);
-			if (METHOD == SA_METHOD_NW) {
-				V[0] = imax3(d[0], V[0], vleft);
-#pragma unroll
-				for (int q = 1; q < K; q++)
-					V[q] = imax3(d[q], V[q], V[q - 1]);
-			} else if (METHOD == SA_METHOD_GA) {
-				int x = shift_in<G>(inj, xout, leader);
-#pragma unroll
-				for (int q = 0; q < K; q++) {
-					const int y = imax(V[q], Y[q]);
-					const int m = imax3(d[q], x, y);
-					Y[q] = y;
-					V[q] = m + gq;
-					x = imax(V[q], x);
-				}
-				xout = x;
-			} else {
-				int x = shift_in<G>(inj, xout, leader);
-				fl = shift_in<G>(inj - go, fl, leader); /* floor = baseline of the row's sequence */
-#pragma unroll
-				for (int q = 0; q < K; q++) {
-					const int y = imax(V[q], Y[q] + ge);
-					const int m = imax(imax3(d[q], x, y), fl);
-					Y[q] = y;
-					V[q] = m + go;
-					x = imax(V[q], x + ge);
-					best = imax(best, m);
-				}
-				xout = x;
-			}
-			vprev = vleft;
+	unsigned long long st_c = 0, st_r = 0, st_steps = 0;
+	for (int32_t strip_i = 0; strip_i < nstrips; strip_i++) {
+		const int32_t strip = LONG ? strip_i : 0; /* a literal 0 in the single-strip kernels */
+		if (strip > 0) {
+			__syncthreads();
 		}
-#pragma unroll
-		for (int k = 0; k < 8; k++)
-			w2[k] = w2n[k];
-		injvec = injvec_next;
-		ev_lo = (ev_lo >> 16) | (ev_hi << 48);
-		ev_hi = fold16(mn);
+		/* ---- query profile of column sequence j for this lane's K column slots ---- */
+		{
+			int bq[K];
+	#pragma unroll
+			for (int q = 0; q < K; q++) {
+				const int c0 = strip * W + lig * K + q - pad;
+				bq[q] = c0 >= 0 ? (int)A.codes[offj + c0] : -1;
+			}
+			/* lanes holding the same columns split the table rows between them */
+			constexpr int SHARE = NT == 2 ? 1 : 64 / NSLOT;          /* builders per slot: 4, 2 or 1 */
+			constexpr int ROWS_EACH = (SA_CODE_ROWS + SHARE - 1) / SHARE;
+			const int slot = lane & (NSLOT - 1);
+			const int a_lo = NT == 2 ? 0 : (lane / NSLOT) * ROWS_EACH;
+			const int a_hi = NT == 2 ? SA_CODE_ROWS : (a_lo + ROWS_EACH < SA_CODE_ROWS ? a_lo + ROWS_EACH : SA_CODE_ROWS);
+			uint8_t *tbl = s_prof + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0);
+			for (int a = a_lo; a < a_hi; a++) {
+				uint32_t w[RB / 4];
+	#pragma unroll
+				for (int k = 0; k < RB / 4; k++)
+					w[k] = 0x80808080u;
+	#pragma unroll
+				for (int q = 0; q < K; q++) {
+					int v = -128;
+					if (a < SA_SUB_DIM && bq[q] >= 0) {
+						v = (int)s_sub[a * SA_SUB_DIM + bq[q]] + A.pconst;
+						/* Gotoh: the first real column sits right of a padding column whose N is
+						 * one q too low (see header): compensate in its diagonal term */
+						if (METHOD == SA_METHOD_GA && pad != 0 && strip * W + lig * K + q == pad)
+							v -= A.q;
+					}
+					w[q >> 2] = (w[q >> 2] & ~(0xffu << (8 * (q & 3)))) | ((uint32_t)(v & 0xff) << (8 * (q & 3)));
+				}
+				uint32_t *dst = reinterpret_cast<uint32_t *>(tbl + a * ROWSTRIDE + slot * RB);
+	#pragma unroll
+				for (int k = 0; k < RB / 4; k++)
+					dst[k] = w[k];
+			}
+		}
+		__syncthreads();
+
+
+		/* ---- row streams: group g streams sequences [ib_g, ib_g + cnt_g) ---- */
+		const int32_t ib_g = i_begin + grp * ch;
+		int32_t cnt_g = i_count - grp * ch;
+		cnt_g = cnt_g < 0 ? 0 : cnt_g > ch ? ch : cnt_g;
+		const int32_t sbeg = A.off[ib_g < A.num ? ib_g : 0];
+		const int32_t slen = cnt_g > 0 ? A.off[ib_g + cnt_g] - sbeg : 0;
+		int32_t smax = 0; /* longest stream of the wave */
+	#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			int32_t c = i_count - g * ch;
+			c = c < 0 ? 0 : c > ch ? ch : c;
+			const int32_t b = i_begin + g * ch;
+			const int32_t l = c > 0 ? A.off[b + c] - A.off[b] : 0;
+			smax = l > smax ? l : smax;
+		}
+		const int32_t steps = smax + G - 1;
+		const int32_t nblk = (steps + 15) >> 4;
+		st_steps += (unsigned long long)nblk * 16;
+		const uint8_t *stream = A.codes + sbeg;
+		/* token prefetch: 16 stream bytes per DPP row and block, fetched two blocks ahead of their use.
+		 * The load is unconditional (clamped address); the out-of-stream select happens when the block is
+		 * converted, so the vmcnt wait lands a full block after the issue. */
+		const int32_t last = slen > 0 ? slen - 1 : 0;
+		const int r16 = lane & 15;
+		auto load_block = [&](int32_t blk) -> int {
+			const int32_t pos = (blk << 4) + r16;
+			return (int)stream[pos < last ? pos : last];
+		};
+		constexpr uint32_t SEPWORD = (uint32_t)SA_CODE_SEP << SH;
+		constexpr uint32_t NOPWORD = (uint32_t)SA_CODE_NOP << SH;
+		auto block_word = [&](int32_t blk, int raw) -> uint32_t { /* token -> profile row address */
+			const int32_t pos = (blk << 4) + r16;
+			return pos < slen ? (uint32_t)raw << SH : NOPWORD;
+		};
+		/* every DPP row writes the ring of the group it belongs to; only the group's first row carries
+		 * the stream (rows 1.. of a 32/64-lane group write a private scratch half that is never read) */
+		uint16_t *ring = s_ring + grp * GSTRIDE; /* copy 0 at [0, 2*RING), copy 1 at [COPY1, COPY1 + 2*RING) */
+		const bool feeder = (lane & (G - 1)) < 16;
+		auto ring_write = [&](int32_t blk, uint32_t word) {
+			if (feeder) {
+				const int p = (blk << 4) + r16;
+				const int i0 = p & (RING - 1), i1 = (p + 1) & (RING - 1);
+				ring[i0] = (uint16_t)word;
+				ring[i0 + RING] = (uint16_t)word;
+				ring[COPY1 + i1] = (uint16_t)word;
+				ring[COPY1 + i1 + RING] = (uint16_t)word;
+			}
+		};
+		/* terminator positions of a block of tokens: wave ballot (bit = lane) */
+		auto sep_ballot = [&](uint32_t word) -> unsigned long long { return __ballot(feeder && word == SEPWORD); };
+		/* any group: wave-uniform 16-bit mask of the block's terminator positions */
+		auto fold16 = [&](unsigned long long m) -> uint32_t {
+			m |= m >> 32;
+			m |= m >> 16;
+			return (uint32_t)m & 0xffffu;
+		};
+
+		/* ---- DP state ---- */
+		int V[K];        /* NW: H'   GA: N     SW: No                               */
+		int Y[K];        /* GA: Y'   SW: Y                                          */
+		int vprev;       /* value of the column left of V[0], previous row (diag)   */
+		int xout;        /* GA/SW: X of the column right of V[K-1], current row     */
+		int fl = 0;      /* SW: floor of the row this lane is processing (travels with the row) */
+		int best = 0, carry = NEG;
+		int nsep = 0;
+		/* boundary value the group's first lane injects on an ordinary row of the FIRST sequence:
+		 * NW  B,  GA  B + 2q,  SW  B + o  (B = 0); a terminator row injects cspecial more (GA: B' + q) */
+		const int inj0 = METHOD == SA_METHOD_NW ? 0 : METHOD == SA_METHOD_GA ? 2 * gq : go;
+		const int cspecial = METHOD == SA_METHOD_GA ? -gq : 0;
+		if (METHOD == SA_METHOD_NW) {
+			vprev = 0;
+			xout = 0;
+	#pragma unroll
+			for (int q = 0; q < K; q++)
+				V[q] = 0, Y[q] = 0;
+		} else if (METHOD == SA_METHOD_GA) {
+			vprev = (leader && strip == 0) ? gq : 2 * gq;
+			xout = gq;
+	#pragma unroll
+			for (int q = 0; q < K; q++)
+				V[q] = 2 * gq, Y[q] = 2 * gq;
+		} else {
+			vprev = go;
+			xout = go;
+	#pragma unroll
+			for (int q = 0; q < K; q++)
+				V[q] = go, Y[q] = go;
+		}
+
+		/* Injection vector of a block: feeder lane k holds the boundary value of the row at stream
+		 * position 16*blk + k, i.e. inj0 + DELTA * (terminators at positions <= that one) (+ cspecial on
+		 * the terminator row itself).  The group's first lane picks entry s at step s with a constant
+		 * row_shl:s DPP, so baseline raises need no branch and no per-step state. */
+		int seps_before = 0; /* terminators of this lane's row-stream in earlier blocks */
+		/* LONG, strips after the first: the boundary a row injects is what the previous strip's last column
+		 * left for that row (scratch), not the baseline; the baseline vector is still needed for the SW floor */
+		auto boundary_vec = [&](const int32_t *line, int32_t blk, int fallback) -> int {
+			const int32_t pos = (blk << 4) + r16;
+			return (LONG && strip > 0) ? line[pos < last ? pos : last] : fallback;
+		};
+		auto inject_vector = [&](unsigned long long m, uint32_t word) -> int {
+			const uint32_t half = (lane & 32) ? (uint32_t)(m >> 32) : (uint32_t)m;
+			const uint32_t seg = (lane & 16) ? half >> 16 : half & 0xffffu;
+			const int incl = __builtin_popcount(seg & ((2u << r16) - 1u));
+			const int v = inj0 + delta * (seps_before + incl) + (word == SEPWORD ? cspecial : 0);
+			seps_before += __builtin_popcount(seg);
+			return v;
+		};
+
+		/* the 16 tokens a lane meets in block blk: stream positions 16*blk - lig + s, two per dword */
+		auto ring_run = [&](int32_t blk, uint32_t (&two)[8]) {
+			const int phase = lig & 1;
+			const uint32_t *rp = reinterpret_cast<const uint32_t *>(
+				ring + phase * COPY1 + (((blk << 4) - lig + phase) & (RING - 1)));
+	#pragma unroll
+			for (int k = 0; k < 8; k++)
+				two[k] = rp[k];
+		};
+		auto tok_of = [&](const uint32_t (&two)[8], int s) -> uint32_t {
+			return (s & 1) ? two[s >> 1] >> 16 : two[s >> 1] & 0xffffu;
+		};
+		auto prof_row = [&](uint32_t word) -> slot_t {
+			return *reinterpret_cast<const slot_t *>(s_prof + (word | slot_off));
+		};
+
+		/* ---- prologue: empty ring, block 0 in the ring, block 1 in flight ---- */
+		for (int k = lane; k < NG * GSTRIDE; k += 64)
+			s_ring[k] = (uint16_t)NOPWORD;
+		__syncthreads();
+		/* terminator bits seen by the LAST lane of a group: position p reaches it G-1 steps late.
+		 * hi bit k = position t0+k (current block), lo bit 64-d = position t0-d */
+		unsigned long long ev_lo = 0, ev_hi;
+		int basevec, injvec, xinjvec;
+		{
+			const uint32_t w0 = block_word(0, load_block(0));
+			ring_write(0, w0);
+			const unsigned long long m0 = sep_ballot(w0);
+			ev_hi = fold16(m0);
+			basevec = inject_vector(m0, w0);
+			injvec = boundary_vec(vb, 0, basevec);
+			xinjvec = boundary_vec(xb, 0, basevec);
+		}
+		int raw_next = load_block(1);
+		__syncthreads();
+		uint32_t w2[8]; /* current block's tokens */
+		ring_run(0, w2);
+		constexpr int PD = 4; /* profile rows are requested PD steps ahead of their use */
+		slot_t pq[PD];
+	#pragma unroll
+		for (int s = 0; s < PD; s++)
+			pq[s] = prof_row(tok_of(w2, s));
+
+		if (A.stamps) {
+			st_c = __builtin_amdgcn_s_memtime();
+			st_r = __builtin_amdgcn_s_memrealtime();
+		}
+		for (int32_t blk = 0; blk < nblk; blk++) {
+			/* steps of this block at which the last lane of some group meets a terminator */
+			const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1))) & 0xffffu);
+			/* next block's tokens go into the ring while this block computes */
+			const uint32_t wn = block_word(blk + 1, raw_next);
+			ring_write(blk + 1, wn);
+			const unsigned long long mn = sep_ballot(wn);
+			const int basevec_next = inject_vector(mn, wn);
+			const int injvec_next = boundary_vec(vb, blk + 1, basevec_next);
+			const int xinjvec_next = boundary_vec(xb, blk + 1, basevec_next);
+			raw_next = load_block(blk + 2);
+			uint32_t w2n[8]; /* next block's tokens, fetched mid-block so no LDS latency is exposed at the seam */
+
+	#pragma unroll
+			for (int s = 0; s < 16; s++) {
+				const slot_t pw = pq[s % PD];
+				if (s == 6)
+					ring_run(blk + 1, w2n);
+				pq[s % PD] = prof_row(s + PD < 16 ? tok_of(w2, s + PD) : tok_of(w2n, s + PD - 16));
+				/* boundary value of this row for the group's first lane */
+				const int inj = dpp_row_shl(injvec, s);
+				const int xinj = (LONG && METHOD != SA_METHOD_NW) ? dpp_row_shl(xinjvec, s) : inj;
+				const int binj = (LONG && METHOD == SA_METHOD_SW) ? dpp_row_shl(basevec, s) : inj;
+				if (METHOD == SA_METHOD_SW) {
+					carry = imax(shift_in<G>(NEG, carry, leader), best);
+				}
+				if (__builtin_expect((ev >> s) & 1u, 0)) { /* wave-uniform, rare: a score leaves the pipeline */
+					/* the empty volatile statement keeps this a scalar branch (s_bitcmp + s_cbranch_scc):
+					 * without it the uniform test is folded into the per-lane one and every step pays
+					 * v_cmp + s_and_saveexec + s_cbranch_execz (measured: +200 cycles per step and wave) */
+					asm volatile("" ::: "memory");
+					if (lig == G - 1 && tok_of(w2, s) == SEPWORD) {
+						if (METHOD == SA_METHOD_SW) /* local: best over all strips of the sequence's columns */
+							s_out[grp * CH + nsep] = (LONG && strip > 0) ? imax(s_out[grp * CH + nsep], carry) : carry;
+						else if (!LONG || strip == nstrips - 1) /* global: the sequence's last column */
+							s_out[grp * CH + nsep] = V[K - 1];
+						nsep++;
+					}
+				}
+				const int vleft = shift_in<G>(inj, V[K - 1], leader);
+				int d[K];
+				d[0] = vprev + slot_byte(pw, 0);
+	#pragma unroll
+				for (int q = 1; q < K; q++)
+					d[q] = V[q - 1] + slot_byte(pw, q);
+				if (METHOD == SA_METHOD_NW) {
+					V[0] = imax3(d[0], V[0], vleft);
+	#pragma unroll
+					for (int q = 1; q < K; q++)
+						V[q] = imax3(d[q], V[q], V[q - 1]);
+				} else if (METHOD == SA_METHOD_GA) {
+					int x = shift_in<G>(xinj, xout, leader);
+	#pragma unroll
+					for (int q = 0; q < K; q++) {
+						const int y = imax(V[q], Y[q]);
+						const int m = imax3(d[q], x, y);
+						Y[q] = y;
+						V[q] = m + gq;
+						x = imax(V[q], x);
+					}
+					xout = x;
+				} else {
+					int x = shift_in<G>(xinj, xout, leader);
+					fl = shift_in<G>(binj - go, fl, leader); /* floor = baseline of the row's sequence */
+	#pragma unroll
+					for (int q = 0; q < K; q++) {
+						const int y = imax(V[q], Y[q] + ge);
+						const int m = imax(imax3(d[q], x, y), fl);
+						Y[q] = y;
+						V[q] = m + go;
+						x = imax(V[q], x + ge);
+						best = imax(best, m);
+					}
+					xout = x;
+				}
+				vprev = vleft;
+				if (LONG && strip + 1 < nstrips && lig == G - 1) { /* park this row's strip boundary */
+					const int32_t pos = (blk << 4) + s - (G - 1);
+					if (pos >= 0 && pos < slen) {
+						vb[pos] = V[K - 1];
+						if (METHOD != SA_METHOD_NW)
+							xb[pos] = xout;
+					}
+				}
+			}
+	#pragma unroll
+			for (int k = 0; k < 8; k++)
+				w2[k] = w2n[k];
+			basevec = basevec_next;
+			injvec = injvec_next;
+			xinjvec = xinjvec_next;
+			ev_lo = (ev_lo >> 16) | (ev_hi << 48);
+			ev_hi = fold16(mn);
+		}
+	if (LONG) {
+		__threadfence_block(); /* parked boundaries visible to this wave's next strip */
+		__syncthreads();
 	}
+	} /* strips */
 	if (A.stamps && lane == 0) {
 		A.stamps[3 * (size_t)t + 0] = __builtin_amdgcn_s_memtime() - st_c;
 		A.stamps[3 * (size_t)t + 1] = __builtin_amdgcn_s_memrealtime() - st_r;
-		A.stamps[3 * (size_t)t + 2] = (unsigned long long)nblk * 16;
+		A.stamps[3 * (size_t)t + 2] = (unsigned long long)st_steps;
 	}
 	__syncthreads();
 
@@ -473,7 +521,7 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 /* Persistent launch: every wave pulls wave-tiles from a device counter until the class is done, so a
  * finished tile is followed by the next one without a workgroup relaunch and the launch drains with at
  * most one tile of imbalance.  (Plain one-tile-per-workgroup grids left ~19 % of the wave slots idle.) */
-template <int METHOD, int G, int K>
+template <int METHOD, int G, int K, bool LONG = false>
 __global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
 {
 	__shared__ int32_t s_next;
@@ -486,7 +534,7 @@ __global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
 		__syncthreads();
 		if (base >= ntiles)
 			break;
-		systolic_tile<METHOD, G, K>(A, base + (int32_t)(threadIdx.x >> 6), ntiles);
+		systolic_tile<METHOD, G, K, LONG>(A, base + (int32_t)(threadIdx.x >> 6), ntiles);
 	}
 }
 
@@ -498,6 +546,9 @@ template <int METHOD> hipError_t launch_method(int cls, const SaSysArgs &a, int 
 		break;
 	switch (cls) {
 		SA_SYS_CLASS_LIST(SA_CASE)
+	case SA_SYS_CLASS_LONG: /* strip-mined: column sequences longer than the widest class */
+		hipLaunchKernelGGL((sa_k_systolic<METHOD, 64, 16, true>), dim3(tiles), dim3(64 * SA_SYS_WPB), 0, s, a);
+		break;
 	default:
 		return hipErrorInvalidValue;
 	}

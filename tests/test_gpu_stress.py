@@ -82,3 +82,16 @@ def test_subranges_and_stream_lengths(sa, oracle, torch_cuda=None):
                 ctx.align_range(a, b - a, out.data_ptr(), stream)
                 torch.cuda.synchronize()
                 assert np.array_equal(out.cpu().numpy(), want[a:b]), (method, a, b)
+
+
+@pytest.mark.parametrize("method,gaps", [("nw", dict(gap_pen=4)), ("ga", dict(gap_open=10, gap_extend=1)),
+                                         ("sw", dict(gap_open=10, gap_extend=1)), ("ga", dict(gap_open=11, gap_extend=11))])
+def test_strip_mined_long_columns(method, gaps, sa, oracle):
+    """column sequences of 1 .. 5 strips (1025 .. 5000 residues) mixed with short ones: every strip count, strip
+    boundaries (n = 1024k, 1024k+1), rows both short and long, enough rows for several stream tiles"""
+    rng = np.random.default_rng(103)
+    lens = [1024, 1025, 2047, 2048, 2049, 3000, 4096, 4097, 5000, 1500]
+    lens = list(rng.integers(1, 200, 60)) + lens + list(rng.integers(900, 1300, 8)) + list(rng.integers(1, 60, 30)) + [2500, 1030]
+    order = rng.permutation(len(lens))
+    seqs = rand_seqs(rng, len(lens), [lens[k] for k in order], AMINO20)
+    check(sa, oracle, seqs, sa.Scoring.from_names(method, "blosum62", **gaps))
