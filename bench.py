@@ -48,11 +48,11 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--n", type=int, default=None, help="override sequence count (parity/debug runs)")
+    ap.add_argument("--n", "--nseq", dest="n", type=int, default=None, help="override sequence count (parity/debug runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the untimed sa_hip_align end-to-end check (profiling runs)")
-    ap.add_argument("--chunks", type=int, default=None, help="super-chunks per step for compute/all-gather overlap (N>1; default 4)")
+    ap.add_argument("--chunks", type=int, default=None, help="super-chunks per step for compute/all-gather overlap (N>1; default: pick 1, 2 or 4 by an untimed trial)")
     return ap.parse_args()
 
 
@@ -124,33 +124,70 @@ def main():
     # strong scaling: total work fixed.  The packed index is cut chunk-major / rank-minor (ChunkedGather) so that
     # the all-gather of super-chunk c overlaps the kernels of super-chunk c+1 and lands in place in packed order.
     use_dist = dist is not None
-    sched = ChunkedGather(pairs, world, rank, (args.chunks or 4) if use_dist else 1)
     ctx = sa.Context(store, scoring, local_rank)
-    packed = torch.zeros(sched.total, dtype=torch.int32, device="cuda")
-    compute = torch.cuda.current_stream()
+    main = torch.cuda.current_stream()
     comm = torch.cuda.Stream() if use_dist else None
-    my_pairs = sum(hi - lo for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
-    my_cells = sum(store.cells(lo, hi - lo) for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
+    side = []
 
-    def step():
-        works = []
-        for c in range(sched.chunks):
-            lo, hi = sched.slice_range(c)
-            ctx.align_range(lo, hi - lo, sched.my_slice(packed, c).data_ptr(), compute.cuda_stream)
+    def schedule(chunks):
+        """(sched, step) for `chunks` super-chunks per step; one compute stream per super-chunk, so the kernels of
+        consecutive super-chunks may overlap while the gather of each starts as soon as its own kernels finish."""
+        sched = ChunkedGather(pairs, world, rank, chunks)
+        while use_dist and len(side) < chunks:
+            side.append(torch.cuda.Stream())
+        streams = side[:chunks] if use_dist else [main]
+
+        def step():
+            works = []
             if use_dist:
-                done = torch.cuda.Event()
-                done.record(compute)
-                with torch.cuda.stream(comm):
-                    comm.wait_event(done)
-                    works.append(dist.all_gather_into_tensor(sched.super_chunk(packed, c), sched.my_slice(packed, c), async_op=True))
-        for w in works:
-            w.wait()  # the compute stream waits for the gathers of this step
+                start = torch.cuda.Event()
+                start.record(main)
+            for c in range(sched.chunks):
+                lo, hi = sched.slice_range(c)
+                cs = streams[c]
+                if use_dist:
+                    cs.wait_event(start)  # ordered after the previous step
+                ctx.align_range(lo, hi - lo, sched.my_slice(packed, c).data_ptr(), cs.cuda_stream)
+                if use_dist:
+                    done = torch.cuda.Event()
+                    done.record(cs)
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(done)
+                        works.append(dist.all_gather_into_tensor(sched.super_chunk(packed, c), sched.my_slice(packed, c), async_op=True))
+            for w in works:
+                w.wait()  # the main stream waits for the gathers (and therefore the kernels) of this step
+        return sched, step
 
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # super-chunks per step: more of them hide more of the all-gather behind the kernels but shorten the kernels'
+    # row streams; the trade depends on the fabric, so (unless --chunks fixes it) it is measured before the warmup,
+    # untimed, and every rank takes the same decision from the max-over-ranks time
+    candidates = [args.chunks] if (args.chunks or not use_dist) else [1, 2, 4]
+    if not use_dist:
+        candidates = [1]
+    packed = torch.zeros(max(ChunkedGather(pairs, world, rank, c).total for c in candidates), dtype=torch.int32, device="cuda")
+    tuned = {}
+    if len(candidates) > 1:
+        for c in candidates:
+            _, trial = schedule(c)
+            trial(); trial()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                trial()
+            fence()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tuned[c] = float(t.item()) / 4 * 1e3
+        candidates = [min(tuned, key=tuned.get)]
+    sched, step = schedule(candidates[0])
+    my_pairs = sum(hi - lo for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
+    my_cells = sum(store.cells(lo, hi - lo) for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
 
     for _ in range(args.warmup):
         step()
@@ -206,7 +243,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], "
                                    f"{cfg['method']} {cfg['matrix']} {cfg['gaps']}, all-vs-all packed triangular",
-                       "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (f" + RCCL all-gather, {sched.chunks} overlapped super-chunks" if use_dist else "")},
+                       "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (f" + RCCL all-gather, {sched.chunks} overlapped super-chunks" if use_dist else ""),
+                       **({"super_chunk_trial_ms": tuned} if tuned else {})},
             "gcups": cells * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,

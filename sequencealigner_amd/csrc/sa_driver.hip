@@ -34,7 +34,12 @@ struct sa_ctx {
 	int32_t *d_scratch = nullptr;
 	int64_t scratch_stride = 0;
 	int generic_blocks = 0;
-	unsigned *d_counters = nullptr; /* one tile counter per systolic class launch (+1: strip-mined launch) */
+	/* tile counters of the persistent launches: one slot of (classes + 1) counters per sa_ctx_align_range
+	 * call, taken round-robin from a ring so that ranges issued back to back on DIFFERENT streams (an
+	 * overlapped multi-chunk schedule) never share a counter */
+	enum { COUNTER_SLOTS = 256, COUNTERS_PER_SLOT = SA_SYS_NCLASSES + 1 };
+	unsigned *d_counters = nullptr;
+	uint64_t call_no = 0;
 	int32_t *d_long_scratch = nullptr; /* strip boundaries of the strip-mined launch, per workgroup   */
 	int64_t long_stride = 0;           /* ints per workgroup                                          */
 	int long_wgs = 0;
@@ -331,7 +336,7 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		blocks = std::max<int64_t>(prop.multiProcessorCount, std::min(blocks, budget / per_block));
 		ctx->generic_blocks = (int)blocks;
 		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
-		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * (SA_SYS_NCLASSES + 1)), break);
+		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * sa_ctx::COUNTER_SLOTS * sa_ctx::COUNTERS_PER_SLOT), break);
 		ctx->persistent_wgs = prop.multiProcessorCount * 32;
 		bool streams_ok = true;
 		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming), streams_ok = false);
@@ -661,8 +666,9 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 	/* systolic streaming kernels: one persistent launch per column-length class; with several classes the
 	 * launches go to side streams forked from / joined back into the caller's stream so they run concurrently */
 	const bool fan_out = ctx->plan->classes.size() > 1 && !getenv("SA_HIP_SERIAL_CLASSES");
+	unsigned *const counters = ctx->d_counters + (ctx->call_no++ % sa_ctx::COUNTER_SLOTS) * sa_ctx::COUNTERS_PER_SLOT;
 	if (!ctx->plan->classes.empty()) {
-		SA_HIP_CHECK(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned) * (SA_SYS_NCLASSES + 1), s), return 1);
+		SA_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(unsigned) * sa_ctx::COUNTERS_PER_SLOT, s), return 1);
 	}
 	if (fan_out) {
 		SA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s), return 1);
@@ -695,7 +701,7 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.gap_o = ctx->sc.gap_opn;
 		a.gap_e = ctx->sc.gap_ext;
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
-		a.counter = ctx->d_counters + cl.cls;
+		a.counter = counters + cl.cls;
 		a.chunk = is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
 		if (is_long) {
 			/* scratch: two lines (V and X) of one tile's longest possible row stream per workgroup,
