@@ -63,7 +63,7 @@ __device__ __forceinline__ int dpp_wave_shr1(int old, int src)
 __device__ __forceinline__ int dpp_row_shl(int v, int n)
 {
 	switch (n) {
-#define SA_SHL(N) case N: return __builtin_amdgcn_update_dpp(0, v, 0x100 + N, 0xf, 0xf, false);
+#define SA_SHL(N) case N: return __builtin_amdgcn_mov_dpp(v, 0x100 + N, 0xf, 0xf, true); /* bound_ctrl: no `old` to initialise */
 		SA_SHL(1) SA_SHL(2) SA_SHL(3) SA_SHL(4) SA_SHL(5) SA_SHL(6) SA_SHL(7) SA_SHL(8)
 		SA_SHL(9) SA_SHL(10) SA_SHL(11) SA_SHL(12) SA_SHL(13) SA_SHL(14) SA_SHL(15)
 #undef SA_SHL
@@ -109,6 +109,12 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 {
 	static_assert(!LONG || (G == 64 && K == 16), "strip mining is instantiated for the widest class only");
 	constexpr int WPB = SA_SYS_WPB; /* waves per workgroup, each wave owns one wave-tile and its own LDS */
+	/* NW / SW, single strip: the boundary value the group's first lane injects is constant between
+	 * terminators (the baseline), so it simply LIVES in the first lane's copy of the shift register: the
+	 * row_shr/wave_shr DPP never writes that lane (no source), and a terminator entering the group raises
+	 * it on the rare event path.  Gotoh (a different value on the terminator row itself) and the strip-mined
+	 * kernel (per-row boundaries from scratch) pick a per-block boundary vector with a second DPP instead. */
+	constexpr bool REGINJ = !LONG && METHOD != SA_METHOD_GA;
 	constexpr int NG = 64 / G;
 	constexpr int W = G * K;
 	constexpr int RB = K <= 4 ? 4 : K <= 8 ? 8 : 16;  /* bytes per profile slot                    */
@@ -122,7 +128,7 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	constexpr int SH = (RB == 4 ? 2 : RB == 8 ? 3 : 4) + (NSLOT == 16 ? 4 : 5);
 	using slot_t = typename Slot<RB>::type;
 
-	constexpr int TBLSTRIDE = 32 * ROWSTRIDE;        /* power of two: address = tok<<SH | slot_off */
+	constexpr int TBLSTRIDE = 32 * ROWSTRIDE;        /* power of two */
 	constexpr int PROF_BYTES = NT == 2 ? 2 * TBLSTRIDE : SA_CODE_ROWS * ROWSTRIDE;
 	__shared__ __attribute__((aligned(16))) uint8_t s_prof_all[WPB * PROF_BYTES];
 	/* s_out (scores leaving the pipeline) is only written after the profile build, which is the only
@@ -144,7 +150,7 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 	__shared__ __attribute__((aligned(16))) uint16_t s_ring_all[WPB * NG * GSTRIDE];
 
 	const int lane = threadIdx.x & 63;
-	const int wv = threadIdx.x >> 6;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	uint8_t *s_prof = s_prof_all + wv * PROF_BYTES;
 	int32_t *s_out = s_out_all + wv * OUT_INTS;
 	int8_t *s_sub = reinterpret_cast<int8_t *>(LONG ? s_out + NG * CH : s_out);
@@ -185,7 +191,8 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		s_sub[k] = A.sub8[k];
 	__syncthreads();
 
-	const uint32_t slot_off = (uint32_t)((lane & (NSLOT - 1)) * RB + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0));
+	/* this lane's slot of profile row 0 (a per-lane LDS address: a token's row is one add away) */
+	const uint8_t *const lane_prof = s_prof + (uint32_t)((lane & (NSLOT - 1)) * RB + (NT == 2 ? (lane >> 5) * TBLSTRIDE : 0));
 	const int32_t delta = A.delta;
 	const int32_t gq = A.q, go = A.gap_o, ge = A.gap_e;
 	unsigned long long st_c = 0, st_r = 0, st_steps = 0;
@@ -296,14 +303,17 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		int V[K];        /* NW: H'   GA: N     SW: No                               */
 		int Y[K];        /* GA: Y'   SW: Y                                          */
 		int vprev;       /* value of the column left of V[0], previous row (diag)   */
+		int vl[2];       /* REGINJ: left-neighbour shift registers of even / odd steps (vprev = the other one) */
 		int xout;        /* GA/SW: X of the column right of V[K-1], current row     */
 		int fl = 0;      /* SW: floor of the row this lane is processing (travels with the row) */
+		int flead = 0;   /* SW, REGINJ: the floor the group's first lane starts a row with (the current baseline) */
 		int best = 0, carry = NEG;
 		int nsep = 0;
 		/* boundary value the group's first lane injects on an ordinary row of the FIRST sequence:
 		 * NW  B,  GA  B + 2q,  SW  B + o  (B = 0); a terminator row injects cspecial more (GA: B' + q) */
 		const int inj0 = METHOD == SA_METHOD_NW ? 0 : METHOD == SA_METHOD_GA ? 2 * gq : go;
 		const int cspecial = METHOD == SA_METHOD_GA ? -gq : 0;
+		vl[0] = vl[1] = inj0;
 		if (METHOD == SA_METHOD_NW) {
 			vprev = 0;
 			xout = 0;
@@ -344,20 +354,19 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 			return v;
 		};
 
-		/* the 16 tokens a lane meets in block blk: stream positions 16*blk - lig + s, two per dword */
-		auto ring_run = [&](int32_t blk, uint32_t (&two)[8]) {
+		/* the 16 tokens a lane meets in block blk: stream positions 16*blk - lig + s, two per dword.  They are
+		 * kept in ONE rolling 8-dword window: dword k (steps 2k, 2k+1) is refilled with the next block's
+		 * tokens at step 2k+2, right after its last use, so no second buffer is live */
+		auto ring_ptr = [&](int32_t blk) -> const uint32_t * {
 			const int phase = lig & 1;
-			const uint32_t *rp = reinterpret_cast<const uint32_t *>(
+			return reinterpret_cast<const uint32_t *>(
 				ring + phase * COPY1 + (((blk << 4) - lig + phase) & (RING - 1)));
-	#pragma unroll
-			for (int k = 0; k < 8; k++)
-				two[k] = rp[k];
 		};
 		auto tok_of = [&](const uint32_t (&two)[8], int s) -> uint32_t {
 			return (s & 1) ? two[s >> 1] >> 16 : two[s >> 1] & 0xffffu;
 		};
 		auto prof_row = [&](uint32_t word) -> slot_t {
-			return *reinterpret_cast<const slot_t *>(s_prof + (word | slot_off));
+			return *reinterpret_cast<const slot_t *>(lane_prof + word);
 		};
 
 		/* ---- prologue: empty ring, block 0 in the ring, block 1 in flight ---- */
@@ -367,20 +376,27 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		/* terminator bits seen by the LAST lane of a group: position p reaches it G-1 steps late.
 		 * hi bit k = position t0+k (current block), lo bit 64-d = position t0-d */
 		unsigned long long ev_lo = 0, ev_hi;
-		int basevec, injvec, xinjvec;
+		int basevec = 0, injvec = 0, xinjvec = 0;
 		{
 			const uint32_t w0 = block_word(0, load_block(0));
 			ring_write(0, w0);
 			const unsigned long long m0 = sep_ballot(w0);
 			ev_hi = fold16(m0);
-			basevec = inject_vector(m0, w0);
-			injvec = boundary_vec(vb, 0, basevec);
-			xinjvec = boundary_vec(xb, 0, basevec);
+			if (!REGINJ) {
+				basevec = inject_vector(m0, w0);
+				injvec = boundary_vec(vb, 0, basevec);
+				xinjvec = boundary_vec(xb, 0, basevec);
+			}
 		}
 		int raw_next = load_block(1);
 		__syncthreads();
-		uint32_t w2[8]; /* current block's tokens */
-		ring_run(0, w2);
+		uint32_t w2[8]; /* rolling token window */
+		{
+			const uint32_t *rp0 = ring_ptr(0);
+	#pragma unroll
+			for (int k = 0; k < 8; k++)
+				w2[k] = rp0[k];
+		}
 		constexpr int PD = 4; /* profile rows are requested PD steps ahead of their use */
 		slot_t pq[PD];
 	#pragma unroll
@@ -393,27 +409,29 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		}
 		for (int32_t blk = 0; blk < nblk; blk++) {
 			/* steps of this block at which the last lane of some group meets a terminator */
-			const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1))) & 0xffffu);
+			/* ... and (REGINJ) steps at which a terminator enters the first lane of some group */
+			const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1)) | (REGINJ ? ev_hi : 0ull)) & 0xffffu);
 			/* next block's tokens go into the ring while this block computes */
 			const uint32_t wn = block_word(blk + 1, raw_next);
 			ring_write(blk + 1, wn);
 			const unsigned long long mn = sep_ballot(wn);
-			const int basevec_next = inject_vector(mn, wn);
-			const int injvec_next = boundary_vec(vb, blk + 1, basevec_next);
-			const int xinjvec_next = boundary_vec(xb, blk + 1, basevec_next);
+			const int basevec_next = REGINJ ? 0 : inject_vector(mn, wn);
+			const int injvec_next = REGINJ ? 0 : boundary_vec(vb, blk + 1, basevec_next);
+			const int xinjvec_next = REGINJ ? 0 : boundary_vec(xb, blk + 1, basevec_next);
 			raw_next = load_block(blk + 2);
-			uint32_t w2n[8]; /* next block's tokens, fetched mid-block so no LDS latency is exposed at the seam */
+			const uint32_t *rpn = ring_ptr(blk + 1);
 
 	#pragma unroll
 			for (int s = 0; s < 16; s++) {
 				const slot_t pw = pq[s % PD];
-				if (s == 6)
-					ring_run(blk + 1, w2n);
-				pq[s % PD] = prof_row(s + PD < 16 ? tok_of(w2, s + PD) : tok_of(w2n, s + PD - 16));
+				if (s >= 2 && (s & 1) == 0)
+					w2[(s - 2) >> 1] = rpn[(s - 2) >> 1];
+				pq[s % PD] = prof_row(tok_of(w2, (s + PD) & 15));
 				/* boundary value of this row for the group's first lane */
-				const int inj = dpp_row_shl(injvec, s);
+				const int inj = REGINJ ? 0 : dpp_row_shl(injvec, s);
 				const int xinj = (LONG && METHOD != SA_METHOD_NW) ? dpp_row_shl(xinjvec, s) : inj;
 				const int binj = (LONG && METHOD == SA_METHOD_SW) ? dpp_row_shl(basevec, s) : inj;
+				int &vcur = vl[s & 1];
 				if (METHOD == SA_METHOD_SW) {
 					carry = imax(shift_in<G>(NEG, carry, leader), best);
 				}
@@ -422,6 +440,12 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 					 * without it the uniform test is folded into the per-lane one and every step pays
 					 * v_cmp + s_and_saveexec + s_cbranch_execz (measured: +200 cycles per step and wave) */
 					asm volatile("" ::: "memory");
+					if (REGINJ && leader && tok_of(w2, s) == SEPWORD) { /* a new sequence starts: raise the baseline */
+						vl[0] += delta;
+						vl[1] += delta;
+						if (METHOD == SA_METHOD_SW)
+							flead += delta;
+					}
 					if (lig == G - 1 && tok_of(w2, s) == SEPWORD) {
 						if (METHOD == SA_METHOD_SW) /* local: best over all strips of the sequence's columns */
 							s_out[grp * CH + nsep] = (LONG && strip > 0) ? imax(s_out[grp * CH + nsep], carry) : carry;
@@ -430,12 +454,18 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 						nsep++;
 					}
 				}
-				const int vleft = shift_in<G>(inj, V[K - 1], leader);
+				if (REGINJ)
+					vprev = vl[(s + 1) & 1];
 				int d[K];
 				d[0] = vprev + slot_byte(pw, 0);
 	#pragma unroll
 				for (int q = 1; q < K; q++)
 					d[q] = V[q - 1] + slot_byte(pw, q);
+				/* the diagonal adds go first: the DPP move below reads V[K-1], written by the last instruction
+				 * of the previous step, and would otherwise need s_nop wait states at the head of the step */
+				if (REGINJ && K >= 3)
+					__builtin_amdgcn_sched_barrier(0);
+				const int vleft = REGINJ ? (vcur = shift_in<G>(vcur, V[K - 1], leader)) : shift_in<G>(inj, V[K - 1], leader);
 				if (METHOD == SA_METHOD_NW) {
 					V[0] = imax3(d[0], V[0], vleft);
 	#pragma unroll
@@ -453,8 +483,9 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 					}
 					xout = x;
 				} else {
-					int x = shift_in<G>(xinj, xout, leader);
-					fl = shift_in<G>(binj - go, fl, leader); /* floor = baseline of the row's sequence */
+					int x = shift_in<G>(REGINJ ? vleft : xinj, xout, leader);
+					fl = REGINJ ? shift_in<G>(flead, fl, leader) /* the first lane: the current baseline */
+						    : shift_in<G>(binj - go, fl, leader); /* floor = baseline of the row's sequence */
 	#pragma unroll
 					for (int q = 0; q < K; q++) {
 						const int y = imax(V[q], Y[q] + ge);
@@ -466,7 +497,8 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 					}
 					xout = x;
 				}
-				vprev = vleft;
+				if (!REGINJ)
+					vprev = vleft;
 				if (LONG && strip + 1 < nstrips && lig == G - 1) { /* park this row's strip boundary */
 					const int32_t pos = (blk << 4) + s - (G - 1);
 					if (pos >= 0 && pos < slen) {
@@ -476,9 +508,7 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 					}
 				}
 			}
-	#pragma unroll
-			for (int k = 0; k < 8; k++)
-				w2[k] = w2n[k];
+			w2[7] = rpn[7];
 			basevec = basevec_next;
 			injvec = injvec_next;
 			xinjvec = xinjvec_next;
@@ -530,19 +560,31 @@ __global__ __launch_bounds__(64 * SA_SYS_WPB) void sa_k_systolic(SaSysArgs A)
 		if (threadIdx.x == 0)
 			s_next = (int32_t)atomicAdd(A.counter, (unsigned)SA_SYS_WPB);
 		__syncthreads();
-		const int32_t base = s_next;
+		/* readfirstlane: the tile index is wave-uniform; telling the compiler so keeps the whole tile
+		 * geometry (binary search, offsets, ranges) in SGPRs instead of ~35 VGPRs */
+		const int32_t base = __builtin_amdgcn_readfirstlane(s_next);
 		__syncthreads();
 		if (base >= ntiles)
 			break;
-		systolic_tile<METHOD, G, K, LONG>(A, base + (int32_t)(threadIdx.x >> 6), ntiles);
+		systolic_tile<METHOD, G, K, LONG>(A, base + __builtin_amdgcn_readfirstlane((int32_t)(threadIdx.x >> 6)), ntiles);
 	}
+}
+
+/* SA_HIP_LDS_PAD=bytes: extra (unused) dynamic LDS per workgroup, to study occupancy (development switch) */
+static unsigned lds_pad()
+{
+	static const unsigned pad = [] {
+		const char *e = getenv("SA_HIP_LDS_PAD");
+		return e ? (unsigned)atoi(e) : 0u;
+	}();
+	return pad;
 }
 
 template <int METHOD> hipError_t launch_method(int cls, const SaSysArgs &a, int tiles, hipStream_t s)
 {
 #define SA_CASE(IDX, G_, K_)                                                                              \
 	case IDX:                                                                                         \
-		hipLaunchKernelGGL((sa_k_systolic<METHOD, G_, K_>), dim3(tiles), dim3(64 * SA_SYS_WPB), 0, s, a);  \
+		hipLaunchKernelGGL((sa_k_systolic<METHOD, G_, K_>), dim3(tiles), dim3(64 * SA_SYS_WPB), lds_pad(), s, a);  \
 		break;
 	switch (cls) {
 		SA_SYS_CLASS_LIST(SA_CASE)
