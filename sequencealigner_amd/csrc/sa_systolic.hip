@@ -109,12 +109,14 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 {
 	static_assert(!LONG || (G == 64 && K == 16), "strip mining is instantiated for the widest class only");
 	constexpr int WPB = SA_SYS_WPB; /* waves per workgroup, each wave owns one wave-tile and its own LDS */
-	/* NW / SW, single strip: the boundary value the group's first lane injects is constant between
-	 * terminators (the baseline), so it simply LIVES in the first lane's copy of the shift register: the
-	 * row_shr/wave_shr DPP never writes that lane (no source), and a terminator entering the group raises
-	 * it on the rare event path.  Gotoh (a different value on the terminator row itself) and the strip-mined
-	 * kernel (per-row boundaries from scratch) pick a per-block boundary vector with a second DPP instead. */
-	constexpr bool REGINJ = !LONG && METHOD != SA_METHOD_GA;
+	/* Single strip: the boundary value the group's first lane injects is constant between terminators (the
+	 * baseline), so it simply LIVES in the first lane's copy of the shift register: the row_shr/wave_shr DPP
+	 * never writes that lane (no source), and a terminator entering the group raises it on the rare event
+	 * path.  Gotoh injects a different value on the terminator row itself (the corner, one q higher): its
+	 * event path sets that and restores the plain value two steps later, when the register is used again.
+	 * Only the strip-mined kernel (per-row boundaries from scratch) picks a per-block boundary vector with a
+	 * second DPP instead. */
+	constexpr bool REGINJ = !LONG;
 	constexpr int NG = 64 / G;
 	constexpr int W = G * K;
 	constexpr int RB = K <= 4 ? 4 : K <= 8 ? 8 : 16;  /* bytes per profile slot                    */
@@ -307,13 +309,14 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		int xout;        /* GA/SW: X of the column right of V[K-1], current row     */
 		int fl = 0;      /* SW: floor of the row this lane is processing (travels with the row) */
 		int flead = 0;   /* SW, REGINJ: the floor the group's first lane starts a row with (the current baseline) */
+		int vbase;       /* GA, REGINJ: the plain boundary value of the current sequence (first lane) */
 		int best = 0, carry = NEG;
 		int nsep = 0;
 		/* boundary value the group's first lane injects on an ordinary row of the FIRST sequence:
 		 * NW  B,  GA  B + 2q,  SW  B + o  (B = 0); a terminator row injects cspecial more (GA: B' + q) */
 		const int inj0 = METHOD == SA_METHOD_NW ? 0 : METHOD == SA_METHOD_GA ? 2 * gq : go;
 		const int cspecial = METHOD == SA_METHOD_GA ? -gq : 0;
-		vl[0] = vl[1] = inj0;
+		vl[0] = vl[1] = vbase = inj0;
 		if (METHOD == SA_METHOD_NW) {
 			vprev = 0;
 			xout = 0;
@@ -322,6 +325,8 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 				V[q] = 0, Y[q] = 0;
 		} else if (METHOD == SA_METHOD_GA) {
 			vprev = (leader && strip == 0) ? gq : 2 * gq;
+			if (REGINJ && leader)
+				vl[1] = gq; /* the corner of the first sequence (restored to the plain value at step 1) */
 			xout = gq;
 	#pragma unroll
 			for (int q = 0; q < K; q++)
@@ -375,7 +380,8 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		__syncthreads();
 		/* terminator bits seen by the LAST lane of a group: position p reaches it G-1 steps late.
 		 * hi bit k = position t0+k (current block), lo bit 64-d = position t0-d */
-		unsigned long long ev_lo = 0, ev_hi;
+		/* Gotoh, REGINJ: the first sequence's corner sits in vl[1] like after a terminator at position -1 */
+		unsigned long long ev_lo = (REGINJ && METHOD == SA_METHOD_GA) ? 1ull << 63 : 0ull, ev_hi;
 		int basevec = 0, injvec = 0, xinjvec = 0;
 		{
 			const uint32_t w0 = block_word(0, load_block(0));
@@ -410,7 +416,10 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 		for (int32_t blk = 0; blk < nblk; blk++) {
 			/* steps of this block at which the last lane of some group meets a terminator */
 			/* ... and (REGINJ) steps at which a terminator enters the first lane of some group */
-			const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1)) | (REGINJ ? ev_hi : 0ull)) & 0xffffu);
+			const unsigned long long ev_in = !REGINJ ? 0ull
+				: METHOD == SA_METHOD_GA ? (ev_hi | (ev_hi << 2) | (ev_lo >> 62)) /* + the restore steps */
+							 : ev_hi;
+			const uint32_t ev = (uint32_t)(((ev_lo >> (64 - (G - 1))) | (ev_hi << (G - 1)) | ev_in) & 0xffffu);
 			/* next block's tokens go into the ring while this block computes */
 			const uint32_t wn = block_word(blk + 1, raw_next);
 			ring_write(blk + 1, wn);
@@ -440,7 +449,15 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 					 * without it the uniform test is folded into the per-lane one and every step pays
 					 * v_cmp + s_and_saveexec + s_cbranch_execz (measured: +200 cycles per step and wave) */
 					asm volatile("" ::: "memory");
-					if (REGINJ && leader && tok_of(w2, s) == SEPWORD) { /* a new sequence starts: raise the baseline */
+					if (REGINJ && METHOD == SA_METHOD_GA) {
+						if (leader) { /* terminator row: the corner; any other event step: the plain value */
+							const bool sep = tok_of(w2, s) == SEPWORD;
+							vbase += sep ? delta : 0;
+							if (sep)
+								vl[(s + 1) & 1] = vbase;
+							vcur = sep ? vbase + cspecial : vbase;
+						}
+					} else if (REGINJ && leader && tok_of(w2, s) == SEPWORD) { /* a new sequence starts: raise the baseline */
 						vl[0] += delta;
 						vl[1] += delta;
 						if (METHOD == SA_METHOD_SW)
@@ -472,7 +489,7 @@ __device__ __forceinline__ void systolic_tile(const SaSysArgs &A, const int32_t 
 					for (int q = 1; q < K; q++)
 						V[q] = imax3(d[q], V[q], V[q - 1]);
 				} else if (METHOD == SA_METHOD_GA) {
-					int x = shift_in<G>(xinj, xout, leader);
+					int x = shift_in<G>(REGINJ ? vleft : xinj, xout, leader);
 	#pragma unroll
 					for (int q = 0; q < K; q++) {
 						const int y = imax(V[q], Y[q]);
