@@ -564,6 +564,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		int32_t chunk = SA_SYS_CHUNK;
 		while (chunk > 8 && count / (4 * chunk) < want_tiles)
 			chunk >>= 1;
+		if (const char *e = getenv("SA_HIP_CHUNK")) /* development switch: fixed stream length */
+			chunk = std::max(1, std::min(SA_SYS_CHUNK, atoi(e)));
 		plan.chunk = chunk;
 	}
 	const int32_t j0 = column_of(start), j1 = column_of(end - 1);

@@ -43,17 +43,25 @@ struct SaGenericArgs {
 };
 
 /* ---- systolic streaming kernels (sa_systolic.hip) ------------------------ */
-#define SA_SYS_CHUNK 64 /* sequences streamed per lane group and wave-tile */
+#define SA_SYS_CHUNK 32 /* sequences streamed per lane group and wave-tile (at most) */
 #ifndef SA_SYS_WPB
 #define SA_SYS_WPB 1    /* waves per workgroup (one wave-tile each)            */
 #endif
-/* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K */
-#define SA_SYS_CLASS_LIST(X)                                                                        \
-	X(0, 16, 1) X(1, 16, 2) X(2, 16, 3)                                                         \
-	X(3, 16, 4) X(4, 16, 5) X(5, 16, 6) X(6, 16, 7) X(7, 16, 8)                                 \
-	X(8, 32, 5) X(9, 32, 6) X(10, 32, 7) X(11, 32, 8)                                           \
-	X(12, 64, 5) X(13, 64, 6) X(14, 64, 7) X(15, 64, 8)                                         \
-	X(16, 64, 10) X(17, 64, 12) X(18, 64, 14) X(19, 64, 16)
+/* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K, ascending.
+ * Every per-step cost of the wave (token, profile read, shifts, event test) is shared by the lane's K
+ * columns, so the classes use the narrowest group that reaches W with K <= 16: W = 8..128 in steps of 8
+ * (G = 8: two interleaved groups per DPP row), 144..256 (G = 16), 288..512 (G = 32), 576..1024 (G = 64). */
+#define SA_SYS_CLASS_LIST(X) \
+	X(0, 8, 1) X(1, 8, 2) X(2, 8, 3) X(3, 8, 4) \
+	X(4, 8, 5) X(5, 8, 6) X(6, 8, 7) X(7, 8, 8) \
+	X(8, 8, 9) X(9, 8, 10) X(10, 8, 11) X(11, 8, 12) \
+	X(12, 8, 13) X(13, 8, 14) X(14, 8, 15) X(15, 8, 16) \
+	X(16, 16, 9) X(17, 16, 10) X(18, 16, 11) X(19, 16, 12) \
+	X(20, 16, 13) X(21, 16, 14) X(22, 16, 15) X(23, 16, 16) \
+	X(24, 32, 9) X(25, 32, 10) X(26, 32, 11) X(27, 32, 12) \
+	X(28, 32, 13) X(29, 32, 14) X(30, 32, 15) X(31, 32, 16) \
+	X(32, 64, 9) X(33, 64, 10) X(34, 64, 11) X(35, 64, 12) \
+	X(36, 64, 13) X(37, 64, 14) X(38, 64, 15) X(39, 64, 16)
 struct SaSysClass {
 	int G, K;
 };

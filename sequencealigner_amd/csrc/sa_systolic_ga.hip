@@ -1,0 +1,5 @@
+/* systolic kernels of one method: see sa_systolic_kernel.inc */
+#include "sa_internal.h"
+#define SA_SYS_METHOD SA_METHOD_GA
+#define SA_SYS_LAUNCH sa_launch_systolic_ga
+#include "sa_systolic_kernel.inc"
