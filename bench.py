@@ -40,6 +40,11 @@ from tests.synth import CONFIGS, make_config  # noqa: E402
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 s32 lane-ops/s
 OPS_PER_CELL = {"nw": 5, "ga": 9, "sw": 11}  # reference op counts (nw.c:29-35, ga.c:47-62, sw.c:39-57)
+# SIMD issue cycles one wave64 DP cell costs at the very least with this kernel's instruction selection, from the
+# measured per-opcode rates at 8 waves/SIMD (profiles/r01_microbench_valu_rates.txt, r01f_microbench_vgpr_banks.txt):
+# SDWA add / v_max3 2.3, v_max_i32 1.77, v_add_u32 1.1   -> nw 2 ops, ga 5 ops, sw 9 ops per cell
+MIN_ISSUE_CYCLES_PER_CELL = {"nw": 2 * 2.3, "ga": 2 * 2.3 + 2 * 1.77 + 1.1, "sw": 2 * 2.3 + 4 * 1.77 + 3 * 1.1}
+SIMDS, SHADER_HZ = 256 * 4, 2.4e9
 
 
 def parse_args():
@@ -253,7 +258,11 @@ def main():
                          "note": "per-class kernels of one range overlap on side streams; durations are per launch as rocprofv3 reports them"},
             "valu": {"gcups_this_rank": kernel_gcups, "reference_ops_per_cell": OPS_PER_CELL[scoring.method_name],
                      "peak_lane_ops_per_s": VALU_LANE_OPS,
-                     "frac_of_valu_peak_at_reference_op_count": kernel_gcups * 1e9 * OPS_PER_CELL[scoring.method_name] / VALU_LANE_OPS},
+                     "frac_of_valu_peak_at_reference_op_count": kernel_gcups * 1e9 * OPS_PER_CELL[scoring.method_name] / VALU_LANE_OPS,
+                     # the bound that actually applies: wave-cells x minimal issue cycles per cell / SIMD cycles available
+                     "min_issue_cycles_per_wave_cell": MIN_ISSUE_CYCLES_PER_CELL[scoring.method_name],
+                     "frac_of_valu_issue_bound": (my_cells / 64) * MIN_ISSUE_CYCLES_PER_CELL[scoring.method_name]
+                                                 / ((elapsed / args.steps) * SIMDS * SHADER_HZ)},
             "device": sa.device_name(local_rank),
         }
         if e2e is not None:
