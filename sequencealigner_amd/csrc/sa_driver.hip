@@ -265,7 +265,9 @@ static void systolic_setup(sa_ctx *ctx)
 		return;
 	/* widest column the fast path will see: padded to whole strips when longer than the widest class */
 	const int64_t wmax = ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W;
-	if ((gain * wmax + slack) * (SA_SYS_CHUNK + 2) >= ((int64_t)1 << 29))
+	/* SW works in a per-row shifted domain: values additionally drift by |e| per stream position of a tile */
+	const int64_t drift = sc.method == SA_METHOD_SW ? (int64_t)SA_SYS_CHUNK * ((int64_t)ctx->max_len + 1) * std::llabs(e) : 0;
+	if ((gain * wmax + slack) * (SA_SYS_CHUNK + 2) + drift >= ((int64_t)1 << 29))
 		return;
 	ctx->sys_ok = true;
 	ctx->sys_pconst = (int32_t)pconst;
