@@ -23,6 +23,26 @@ for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursiv
     for r in rows[:12]:
         print("  {Name:60s} calls={Calls:>5s} total_ns={TotalDurationNs:>14s} avg_ns={AverageNs:>14s} pct={Percentage}".format(**r))
 
+# the same run seen by bench.py (HIP events around the dominant kernel) next to rocprofv3's per-dispatch durations:
+# the first dispatch of every kernel belongs to the untimed warmup step (bench runs with --warmup 1 here)
+tb = os.path.join(d, "trace_bench.json")
+if os.path.exists(tb):
+    j = json.loads(open(tb).read().strip().splitlines()[-1])
+    roof = j["roofline"]
+    print(f"\n## dominant kernel under rocprofv3: bench.py (HIP events, timed steps) {roof['kernel']} avg {roof['kernel_avg_ms']:.3f} ms")
+    import re
+    m = re.match(r"sa_k_systolic<(\w+),G(\d+),K(\d+)>", roof["kernel"])
+    if m:
+        meth = {"nw": "0", "ga": "1", "sw": "2"}[m.group(1)]
+        pat = f"sa_k_systolic<{meth}, {m.group(2)}, {m.group(3)}, false>"
+        for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
+            durs = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+                    for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
+            durs = [x for _, x in sorted(durs)]
+            if len(durs) > 1:
+                print("   rocprofv3 dispatch durations (ms): " + "  ".join(f"{x:.2f}" for x in durs)
+                      + f"   -> timed dispatches avg {sum(durs[1:]) / len(durs[1:]):.3f} ms (all {sum(durs) / len(durs):.3f})")
+
 # per-dispatch counters, aggregated per kernel
 def agg(sub, counters):
     acc = defaultdict(lambda: defaultdict(float))
