@@ -98,3 +98,19 @@ def test_strip_mined_long_columns(method, gaps, sa, oracle):
     order = rng.permutation(len(lens))
     seqs = rand_seqs(rng, len(lens), [lens[k] for k in order], AMINO20)
     check(sa, oracle, seqs, sa.Scoring.from_names(method, "blosum62", **gaps))
+
+
+@pytest.mark.parametrize("method,gaps", [("nw", dict(gap_pen=4)), ("ga", dict(gap_open=10, gap_extend=1)),
+                                         ("sw", dict(gap_open=10, gap_extend=1)), ("sw", dict(gap_open=5, gap_extend=0))])
+def test_tile_geometry(method, gaps, sa, oracle):
+    """row counts around whole wave-tiles (8 lane groups x 32 sequences) and degenerate streams: all sequences of
+    length 1, length-1 sequences between long ones (terminators two steps apart), identical sequences"""
+    rng = np.random.default_rng(104)
+    scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+    for n in (2, 3, 9, 255, 256, 257, 300, 513):
+        check(sa, oracle, rand_seqs(rng, n, rng.integers(4, 22, n), AMINO20), scoring)
+    check(sa, oracle, rand_seqs(rng, 300, np.ones(300, dtype=int), AMINO20), scoring)
+    lens = np.where(np.arange(200) % 2 == 0, 1, rng.integers(90, 130, 200))
+    check(sa, oracle, rand_seqs(rng, 200, lens, AMINO20), scoring)
+    one = rand_seqs(rng, 1, [77], AMINO20)[0]
+    check(sa, oracle, [one] * 70, scoring)
