@@ -211,6 +211,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N>1: every rank re-scores a few random windows of the gathered vector with its own kernels (untimed) and
+    # compares -- the gathered result of the last step must be the packed matrix in natural order on every GPU
+    gather_ok = None
+    if use_dist:
+        vrng = np.random.default_rng(1234 + rank)
+        okflag = 1
+        for _ in range(6):
+            w = int(min(pairs, 65536))
+            a0 = int(vrng.integers(0, pairs - w + 1))
+            chk = torch.empty(w, dtype=torch.int32, device="cuda")
+            ctx.align_range(a0, w, chk.data_ptr(), main.cuda_stream)
+            torch.cuda.synchronize()
+            if not torch.equal(chk, packed[a0:a0 + w]):
+                okflag = 0
+        t = torch.tensor([okflag], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        gather_ok = bool(t.item())
+
     # end-to-end through the host boundary (upload + kernels + D2H of the packed result), rank 0, N=1 only
     e2e = None
     if world == 1 and not args.no_host_boundary:
@@ -249,7 +267,8 @@ def main():
             "config": {"workload": f"{args.config}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], "
                                    f"{cfg['method']} {cfg['matrix']} {cfg['gaps']}, all-vs-all packed triangular",
                        "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (f" + RCCL all-gather, {sched.chunks} overlapped super-chunks" if use_dist else ""),
-                       **({"super_chunk_trial_ms": tuned} if tuned else {})},
+                       **({"super_chunk_trial_ms": tuned} if tuned else {}),
+                       **({"gathered_result_verified_on_every_rank": gather_ok} if gather_ok is not None else {})},
             "gcups": cells * args.steps / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
