@@ -235,6 +235,7 @@ def main():
         t1 = time.perf_counter()
         host = sa.hip_align(store, scoring, triangular=True)
         e2e = time.perf_counter() - t1
+        e2e_phase = sa.last_align_seconds()
         assert np.array_equal(host, packed[:pairs].cpu().numpy()), "host-boundary result differs from device-resident result"
 
     if rank == 0:
@@ -286,7 +287,9 @@ def main():
         }
         if e2e is not None:
             out["host_boundary"] = {"seconds": e2e, "pairs_per_s": pairs / e2e,
-                                    "note": "sa_hip_align: encode+upload+kernels+D2H into pageable host memory (PCIe-inclusive)"}
+                                    "align_phase_seconds": e2e_phase, "align_phase_pairs_per_s": pairs / e2e_phase if e2e_phase > 0 else None,
+                                    "note": "sa_hip_align: encode+upload+kernels+D2H into pageable host memory (PCIe-inclusive); "
+                                            "align_phase = its launch/copy loop only, the phase the reference times (SURVEY 8d)"}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(seqs, cfg, args.cpu_seconds)
         elif not args.no_cpu_baseline:

@@ -167,6 +167,11 @@ const char *sa_method_name(int method);   /* long alias, e.g. "Gotoh"       */
 int sa_method_gap_kind(int method);       /* enum sa_gap_kind               */
 
 /* ---- misc ---------------------------------------------------------------- */
+/* Seconds the launch/copy loop of the last successful sa_hip_align() took: the phase the reference
+ * brackets with bench_align_start()/bench_align_end() (src/interface/seqalign_cuda.c:182,292 --
+ * uploads, allocations and context set-up are outside it, the device->host copies inside). */
+double sa_hip_last_align_seconds(void);
+
 int sa_hip_device_count(void);
 const char *sa_hip_device_name(int device);
 const char *sa_last_error(void);

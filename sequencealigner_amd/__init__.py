@@ -24,6 +24,7 @@ from .binding import (  # noqa: F401
     SequenceStore,
     device_count,
     device_name,
+    last_align_seconds,
     hip_align,
     hip_filter,
     hip_memory,
@@ -35,6 +36,6 @@ from .binding import (  # noqa: F401
 )
 
 __all__ = [
-    "AlignError", "Context", "Scoring", "SequenceStore", "device_count", "device_name", "hip_align", "hip_filter",
+    "AlignError", "Context", "Scoring", "SequenceStore", "device_count", "device_name", "last_align_seconds", "hip_align", "hip_filter",
     "hip_memory", "library_path", "load_library", "matrix_names", "method_names", "pair_count",
 ]

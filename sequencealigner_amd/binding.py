@@ -50,6 +50,7 @@ ABI_SYMBOLS = (
     "sa_matrix_load", "sa_matrix_count", "sa_matrix_name", "sa_matrix_is_nucleotide", "sa_method_parse",
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
+    "sa_hip_last_align_seconds",
 )
 
 
@@ -130,6 +131,7 @@ def load_library() -> C.CDLL:
     lib.sa_hip_device_name.restype = C.c_char_p
     lib.sa_last_error.restype = C.c_char_p
     lib.sa_abi_version.restype = C.c_int
+    lib.sa_hip_last_align_seconds.restype = C.c_double
     _lib = lib
     return lib
 
@@ -140,6 +142,11 @@ def _err() -> str:
 
 def device_count() -> int:
     return int(load_library().sa_hip_device_count())
+
+
+def last_align_seconds() -> float:
+    """launch/copy phase of the last hip_align call (the reference's bench_align bracket, seqalign_cuda.c:182,292)"""
+    return float(load_library().sa_hip_last_align_seconds())
 
 
 def device_name(device: int = 0) -> str:

@@ -18,6 +18,8 @@
 #include <thread>
 
 #include "sa_internal.h"
+#include <atomic>
+#include <chrono>
 
 struct sa_ctx {
 	int device = 0;
@@ -916,7 +918,7 @@ void host_scatter_full(int32_t *matrix, size_t dim, const int32_t *slice, int64_
 
 /* one device: computes packed range [lo,hi) and delivers it to the host matrix */
 bool run_device_range(int device, const sa_input &in, const sa_output &out, const sa_scoring &sc, int64_t lo,
-		      int64_t hi, bool whole_job, std::string &err)
+		      int64_t hi, bool whole_job, std::string &err, double &phase_seconds)
 {
 	sa_ctx *ctx = sa_ctx_create(device, in, &sc);
 	if (!ctx) {
@@ -947,6 +949,7 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 			if ((long double)need * 4 / 3 < (long double)free_b) {
 				SA_HIP_CHECK(hipMalloc(&d_buf[0], sizeof(int32_t) * (size_t)total), break);
 				SA_HIP_CHECK(hipMalloc(&d_full, sizeof(int32_t) * dim * dim), break);
+				const auto t_phase = std::chrono::steady_clock::now();
 				if (sa_ctx_align_range(ctx, lo, total, d_buf[0], compute))
 					break;
 				if (sa_ctx_expand_full(ctx, d_buf[0], d_full, compute))
@@ -960,6 +963,7 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 				SA_HIP_CHECK(hipMemcpyAsync(out.matrix, d_full, sizeof(int32_t) * dim * dim,
 							    hipMemcpyDeviceToHost, compute), break);
 				SA_HIP_CHECK(hipStreamSynchronize(compute), break);
+				phase_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
 				ok = true;
 				break;
 			}
@@ -987,6 +991,7 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 				(void)hipGetLastError();
 		}
 		{
+			const auto t_phase = std::chrono::steady_clock::now();
 			int64_t issued = 0, delivered = 0;
 			int nb = 0;
 			struct Pending {
@@ -1037,6 +1042,7 @@ bool run_device_range(int device, const sa_input &in, const sa_output &out, cons
 				break;
 			SA_HIP_CHECK(hipStreamSynchronize(compute), break);
 			SA_HIP_CHECK(hipStreamSynchronize(copy), break);
+			phase_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
 			(void)delivered;
 		}
 		ok = true;
@@ -1067,6 +1073,9 @@ out:
 }
 
 } // namespace
+
+/* launch/copy phase of the last successful sa_hip_align call (the reference's bench_align_start..end bracket) */
+static std::atomic<double> g_last_align_seconds{ 0.0 };
 
 extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const struct sa_scoring *sc)
 {
@@ -1100,10 +1109,12 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 		ndev = 1;
 	if (ndev == 1) {
 		std::string err;
-		if (!run_device_range(0, in, out, *sc, 0, pairs, true, err)) {
+		double phase = 0.0;
+		if (!run_device_range(0, in, out, *sc, 0, pairs, true, err, phase)) {
 			sa_set_error("%s", err.c_str());
 			return false;
 		}
+		g_last_align_seconds.store(phase);
 		return true;
 	}
 	/* several devices in one process: range-partition the packed index by DP work, one host
@@ -1114,10 +1125,11 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 	std::vector<std::thread> threads;
 	std::vector<std::string> errs((size_t)ndev);
 	std::vector<char> oks((size_t)ndev, 0);
+	std::vector<double> phases((size_t)ndev, 0.0);
 	for (int d = 0; d < ndev; d++)
 		threads.emplace_back([&, d]() {
 			oks[(size_t)d] = run_device_range(d % nvisible, in, out, *sc, bounds[(size_t)d],
-							  bounds[(size_t)d + 1], false, errs[(size_t)d]);
+							  bounds[(size_t)d + 1], false, errs[(size_t)d], phases[(size_t)d]);
 		});
 	for (auto &t : threads)
 		t.join();
@@ -1126,5 +1138,11 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 			sa_set_error("device %d: %s", d, errs[(size_t)d].c_str());
 			return false;
 		}
+	g_last_align_seconds.store(*std::max_element(phases.begin(), phases.end()));
 	return true;
+}
+
+extern "C" double sa_hip_last_align_seconds(void)
+{
+	return g_last_align_seconds.load();
 }
