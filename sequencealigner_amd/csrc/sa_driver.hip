@@ -588,7 +588,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 			continue;
 		}
 		/* strip-mined tiles stream one group of at most 16 sequences (their scratch lines are per position) */
-		const int rows = cls == SA_SYS_CLASS_LONG ? std::min(plan.chunk, 16) : (64 / SA_SYS_CLASSES[cls].G) * plan.chunk;
+		const int rows = cls == SA_SYS_CLASS_LONG ? std::min(plan.chunk, 16)
+							   : SA_SYS_WPB(SA_SYS_CLASSES[cls].G, false) * (64 / SA_SYS_CLASSES[cls].G) * plan.chunk;
 		if (tp[(size_t)cls].empty())
 			tp[(size_t)cls].push_back(0);
 		const int64_t tiles = (ib - ia + rows - 1) / rows;
@@ -738,7 +739,7 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		if (!timed_begin(e0, e1))
 			return 1;
 		const int wgs = (int)std::min<int64_t>(is_long ? ctx->long_wgs : ctx->persistent_wgs,
-						       (cl.ntiles + SA_SYS_WPB - 1) / SA_SYS_WPB);
+						       cl.ntiles);
 		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
 		if (d_stamps) {
 			std::vector<unsigned long long> h(3 * (size_t)cl.ntiles);

@@ -44,9 +44,10 @@ struct SaGenericArgs {
 
 /* ---- systolic streaming kernels (sa_systolic.hip) ------------------------ */
 #define SA_SYS_CHUNK 32 /* sequences streamed per lane group and wave-tile (at most) */
-#ifndef SA_SYS_WPB
-#define SA_SYS_WPB 1    /* waves per workgroup (one wave-tile each)            */
-#endif
+/* waves per workgroup of a class launch.  The wide groups need a large query profile (26 rows x W bytes: 13 KB
+ * at W = 512, 27 KB at W = 1024), so four waves share one: a workgroup-tile is one column against 4 x (64/G) row
+ * streams, each wave streaming its own groups.  The strip-mined launch keeps one wave (per-workgroup scratch). */
+#define SA_SYS_WPB(G, LONG) ((LONG) ? 1 : (G) >= 32 ? 4 : 1)
 /* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K, ascending.
  * Every per-step cost of the wave (token, profile read, shifts, event test) is shared by the lane's K
  * columns, so the classes use the narrowest group that reaches W with K <= 16: W = 8..128 in steps of 8
