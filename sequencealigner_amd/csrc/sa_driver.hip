@@ -588,7 +588,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 			continue;
 		}
 		/* strip-mined tiles stream one group of at most 16 sequences (their scratch lines are per position) */
-		const int rows = cls == SA_SYS_CLASS_LONG ? std::min(plan.chunk, 16)
+		const int rows = cls == SA_SYS_CLASS_LONG ? SA_SYS_WPB(64, true) * std::min(plan.chunk, 16)
 							   : SA_SYS_WPB(SA_SYS_CLASSES[cls].G, false) * (64 / SA_SYS_CLASSES[cls].G) * plan.chunk;
 		if (tp[(size_t)cls].empty())
 			tp[(size_t)cls].push_back(0);
@@ -711,13 +711,14 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.counter = counters + cl.cls;
 		a.chunk = is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
 		if (is_long) {
-			/* scratch: two lines (V and X) of one tile's longest possible row stream per workgroup,
-			 * as many workgroups as fit a 4 GiB budget */
+			/* scratch: two lines (V and X) of a wave's longest possible row stream, for every wave of as many
+			 * workgroups as fit a 4 GiB budget */
 			if (!ctx->d_long_scratch) {
 				ctx->long_stride = 2 * (16 * ((int64_t)ctx->max_len + 1) + 64);
 				const int64_t budget_ints = ((int64_t)4 << 30) / 4;
-				ctx->long_wgs = (int)std::max<int64_t>(64, std::min<int64_t>(ctx->persistent_wgs / 4, budget_ints / ctx->long_stride));
-				SA_HIP_CHECK(hipMalloc(&ctx->d_long_scratch, sizeof(int32_t) * (size_t)(ctx->long_stride * ctx->long_wgs)), return 1);
+				const int64_t wpb = SA_SYS_WPB(64, true); /* one pair of lines per wave */
+				ctx->long_wgs = (int)std::max<int64_t>(16, std::min<int64_t>(ctx->persistent_wgs / 4, budget_ints / (ctx->long_stride * wpb)));
+				SA_HIP_CHECK(hipMalloc(&ctx->d_long_scratch, sizeof(int32_t) * (size_t)(ctx->long_stride * ctx->long_wgs * wpb)), return 1);
 			}
 			a.long_scratch = ctx->d_long_scratch;
 			a.long_stride = ctx->long_stride;

@@ -46,8 +46,8 @@ struct SaGenericArgs {
 #define SA_SYS_CHUNK 32 /* sequences streamed per lane group and wave-tile (at most) */
 /* waves per workgroup of a class launch.  The wide groups need a large query profile (26 rows x W bytes: 13 KB
  * at W = 512, 27 KB at W = 1024), so four waves share one: a workgroup-tile is one column against 4 x (64/G) row
- * streams, each wave streaming its own groups.  The strip-mined launch keeps one wave (per-workgroup scratch). */
-#define SA_SYS_WPB(G, LONG) ((LONG) ? 1 : (G) >= 32 ? 4 : 1)
+ * streams, each wave streaming its own groups (the strip-mined launch included: scratch lines are per wave). */
+#define SA_SYS_WPB(G, LONG) ((G) >= 32 ? 4 : 1)
 /* kernel classes: (index, lanes per group G, columns per lane K); column budget W = G*K, ascending.
  * Every per-step cost of the wave (token, profile read, shifts, event test) is shared by the lane's K
  * columns, so the classes use the narrowest group that reaches W with K <= 16: W = 8..128 in steps of 8
@@ -89,8 +89,8 @@ struct SaSysArgs {
 	int32_t gap_g, gap_o, gap_e;
 	int32_t delta;           /* baseline raise per sequence                                           */
 	int32_t chunk;           /* sequences per group stream of a wave-tile, 1..SA_SYS_CHUNK            */
-	int32_t *long_scratch;   /* strip-mined launch: per workgroup 2 lines of long_stride/2 ints       */
-	int64_t long_stride;     /* ints per workgroup (>= 2 * longest row stream of a tile)              */
+	int32_t *long_scratch;   /* strip-mined launch: per wave 2 lines of long_stride/2 ints            */
+	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
