@@ -14,6 +14,7 @@ AA = np.frombuffer(b"ARNDCQEGHILKMFPSTWYVBZX", dtype=np.uint8)
 NT = np.frombuffer(b"ACGTN", dtype=np.uint8)
 MATS = ["blosum62", "blosum45", "blosum80", "blosum100", "blosum30", "pam30", "pam70", "pam250", "pam500"]
 t0, cases, bad, generic = time.time(), 0, 0, 0
+last_note = t0
 while time.time() - t0 < budget:
     method = ["nw", "ga", "sw"][int(rng.integers(0, 3))]
     dna = rng.random() < 0.2
@@ -48,6 +49,9 @@ while time.time() - t0 < budget:
     want = o.align(store, sc, triangular=True)
     got = sa.hip_align(store, sc, triangular=True)
     cases += 1
+    if time.time() - last_note > 30:
+        last_note = time.time()
+        print(f"... {cases} cases, {bad} mismatching, {time.time() - t0:.0f} s", flush=True)
     if not np.array_equal(got, want):
         bad += 1
         k = int(np.nonzero(got != want)[0][0])
