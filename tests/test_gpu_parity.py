@@ -75,6 +75,19 @@ def test_edge_shapes(sa, oracle):
             assert np.array_equal(sa.hip_align(store, sc, triangular=False), oracle.align(store, sc, triangular=False))
 
 
+def test_align_phase_timer(sa):
+    """sa_hip_last_align_seconds(): the launch/copy phase of the last call -- positive and inside the call's wall time"""
+    import time
+    store = sa.SequenceStore.from_sequences(make_protein_set(600, 50, 150, 9))
+    scoring = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
+    for triangular in (True, False):
+        t0 = time.perf_counter()
+        sa.hip_align(store, scoring, triangular=triangular)
+        wall = time.perf_counter() - t0
+        phase = sa.last_align_seconds()
+        assert 0.0 < phase <= wall
+
+
 def test_multi_device_driver_path(sa, oracle, monkeypatch):
     """sa_hip_align's several-devices-in-one-process path (work-balanced slices, one host thread per slice,
     slices delivered straight into the host matrix), exercised on one GPU through SA_HIP_SPLIT."""
