@@ -134,6 +134,10 @@ def main():
     comm = torch.cuda.Stream() if use_dist else None
     side = []
 
+    # exchange format of the all-gather: int16 when every score of this workload provably fits (half the bytes over
+    # xGMI); the gathered vector is widened to the reference's s32 on every GPU inside the timed step
+    use16 = use_dist and ctx.scores_fit16 and not os.environ.get("SA_BENCH_GATHER32")
+
     def schedule(chunks):
         """(sched, step) for `chunks` super-chunks per step; one compute stream per super-chunk, so the kernels of
         consecutive super-chunks may overlap while the gather of each starts as soon as its own kernels finish."""
@@ -152,15 +156,23 @@ def main():
                 cs = streams[c]
                 if use_dist:
                     cs.wait_event(start)  # ordered after the previous step
-                ctx.align_range(lo, hi - lo, sched.my_slice(packed, c).data_ptr(), cs.cuda_stream)
+                buf = packed16 if use16 else packed
+                if use16:
+                    ctx.align_range16(lo, hi - lo, sched.my_slice(buf, c).data_ptr(), cs.cuda_stream)
+                else:
+                    ctx.align_range(lo, hi - lo, sched.my_slice(buf, c).data_ptr(), cs.cuda_stream)
                 if use_dist:
                     done = torch.cuda.Event()
                     done.record(cs)
                     with torch.cuda.stream(comm):
                         comm.wait_event(done)
-                        works.append(dist.all_gather_into_tensor(sched.super_chunk(packed, c), sched.my_slice(packed, c), async_op=True))
+                        # (the process group moves bytes; int16 is not among its dtypes, uint8 is)
+                        works.append(dist.all_gather_into_tensor(sched.super_chunk(buf, c).view(torch.uint8),
+                                                                 sched.my_slice(buf, c).view(torch.uint8), async_op=True))
             for w in works:
                 w.wait()  # the main stream waits for the gathers (and therefore the kernels) of this step
+            if use16:
+                ctx.widen16(packed16.data_ptr(), packed.data_ptr(), sched.total, main.cuda_stream)
         return sched, step
 
     def fence():
@@ -176,6 +188,7 @@ def main():
     if not use_dist:
         candidates = [1]
     packed = torch.zeros(max(ChunkedGather(pairs, world, rank, c).total for c in candidates), dtype=torch.int32, device="cuda")
+    packed16 = torch.zeros(packed.numel(), dtype=torch.int16, device="cuda") if use16 else None
     tuned = {}
     if len(candidates) > 1:
         for c in candidates:
@@ -267,7 +280,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], "
                                    f"{cfg['method']} {cfg['matrix']} {cfg['gaps']}, all-vs-all packed triangular",
-                       "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (f" + RCCL all-gather, {sched.chunks} overlapped super-chunks" if use_dist else ""),
+                       "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (f" + RCCL all-gather ({'int16 exchange, widened to s32 on device' if use16 else 's32'}), {sched.chunks} overlapped super-chunks" if use_dist else ""),
                        **({"super_chunk_trial_ms": tuned} if tuned else {}),
                        **({"gathered_result_verified_on_every_rank": gather_ok} if gather_ok is not None else {})},
             "gcups": cells * args.steps / elapsed / 1e9,

@@ -127,6 +127,15 @@ int64_t sa_ctx_pairs(const sa_ctx *ctx);
  * (a hipStream_t, NULL = default stream). 0 on success. */
 int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream);
 
+/* Exchange format for the multi-GPU all-gather (no reference counterpart: SURVEY 8e): the same scores as
+ * int16 when they provably fit -- every |score| <= max_len * max|S| + 2 * max_len * max|gap| <= 32767 for this
+ * store and scoring (sa_ctx_scores_fit16) -- so that the collective moves half the bytes; sa_hip_widen16 turns
+ * the gathered vector back into the reference's s32 on the device.  sa_ctx_align_range16 fails when the bound
+ * does not hold. */
+int sa_ctx_scores_fit16(const sa_ctx *ctx);
+int sa_ctx_align_range16(sa_ctx *ctx, int64_t start, int64_t count, int16_t *d_scores, void *stream);
+int sa_hip_widen16(const int16_t *d_src, int32_t *d_dst, int64_t count, void *stream);
+
 /* Packed triangular (device) -> full symmetric dim x dim with zero diagonal
  * (device), the layout of src/io/output.c:76-81.  Asynchronous on `stream`. */
 int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t *d_full, void *stream);

@@ -46,7 +46,7 @@ class _Scoring(C.Structure):  # struct sa_scoring
 #: every symbol include/seqalign_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
     "sa_hip_memory", "sa_hip_align", "sa_hip_filter", "sa_ctx_create", "sa_ctx_destroy", "sa_ctx_pairs", "sa_pairs_cells",
-    "sa_ctx_align_range", "sa_ctx_expand_full", "sa_pairs_partition", "sa_ctx_timing", "sa_ctx_timing_read",
+    "sa_ctx_align_range", "sa_ctx_align_range16", "sa_ctx_scores_fit16", "sa_hip_widen16", "sa_ctx_expand_full", "sa_pairs_partition", "sa_ctx_timing", "sa_ctx_timing_read",
     "sa_matrix_load", "sa_matrix_count", "sa_matrix_name", "sa_matrix_is_nucleotide", "sa_method_parse",
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
@@ -104,6 +104,12 @@ def load_library() -> C.CDLL:
     lib.sa_pairs_cells.restype = C.c_int64
     lib.sa_ctx_align_range.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
     lib.sa_ctx_align_range.restype = C.c_int
+    lib.sa_ctx_align_range16.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    lib.sa_ctx_align_range16.restype = C.c_int
+    lib.sa_ctx_scores_fit16.argtypes = [C.c_void_p]
+    lib.sa_ctx_scores_fit16.restype = C.c_int
+    lib.sa_hip_widen16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.sa_hip_widen16.restype = C.c_int
     lib.sa_ctx_expand_full.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.sa_ctx_expand_full.restype = C.c_int
     lib.sa_pairs_partition.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.POINTER(C.c_int64)]
@@ -363,6 +369,21 @@ class Context:
 
     def align_range(self, start: int, count: int, d_scores_ptr: int, stream: int = 0) -> None:
         if self._lib.sa_ctx_align_range(self._h, start, count, C.c_void_p(d_scores_ptr), C.c_void_p(stream)):
+            raise AlignError(_err())
+
+    @property
+    def scores_fit16(self) -> bool:
+        """every score of this store under this scoring provably fits int16 (exchange format of the all-gather)"""
+        return bool(self._lib.sa_ctx_scores_fit16(self._h))
+
+    def align_range16(self, start: int, count: int, d_scores16_ptr: int, stream: int = 0) -> None:
+        """as align_range, into an int16 device array; raises when scores_fit16 is False"""
+        if self._lib.sa_ctx_align_range16(self._h, start, count, C.c_void_p(d_scores16_ptr), C.c_void_p(stream)):
+            raise AlignError(_err())
+
+    def widen16(self, d_src16_ptr: int, d_dst32_ptr: int, count: int, stream: int = 0) -> None:
+        """int16 exchange format -> the reference's s32, on the device"""
+        if self._lib.sa_hip_widen16(C.c_void_p(d_src16_ptr), C.c_void_p(d_dst32_ptr), count, C.c_void_p(stream)):
             raise AlignError(_err())
 
     def expand_full(self, d_packed_ptr: int, d_full_ptr: int, stream: int = 0) -> None:

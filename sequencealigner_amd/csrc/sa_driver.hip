@@ -640,7 +640,52 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 
 static const char *const METHOD_TAG[] = { "nw", "ga", "sw" };
 
+static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16);
+
 extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream)
+{
+	return align_range_impl(ctx, start, count, d_scores, stream, false);
+}
+
+/* Largest |score| any pair of this store can reach under this scoring, from lengths, matrix extremes and gaps */
+static int64_t score_magnitude_bound(const sa_ctx *ctx)
+{
+	int64_t smax = 0;
+	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++)
+		smax = std::max<int64_t>(smax, std::llabs((long long)ctx->sc.sub[k]));
+	const int64_t L = ctx->max_len;
+	const int64_t gap = std::max<int64_t>(std::llabs((long long)ctx->sc.gap_pen),
+					      std::max<int64_t>(std::llabs((long long)ctx->sc.gap_opn), std::llabs((long long)ctx->sc.gap_ext)));
+	/* an alignment path has at most L substitution steps and at most 2L gap steps, each gap step costing at
+	 * most `gap` (an opened gap costs open OR extend per position in this model) */
+	return L * smax + 2 * L * gap;
+}
+
+extern "C" int sa_ctx_scores_fit16(const sa_ctx *ctx)
+{
+	return ctx && score_magnitude_bound(ctx) <= 32767 ? 1 : 0;
+}
+
+extern "C" int sa_ctx_align_range16(sa_ctx *ctx, int64_t start, int64_t count, int16_t *d_scores, void *stream)
+{
+	if (!sa_ctx_scores_fit16(ctx)) {
+		sa_set_error("sa_ctx_align_range16: scores of this store and scoring are not provably within int16");
+		return 1;
+	}
+	return align_range_impl(ctx, start, count, reinterpret_cast<int32_t *>(d_scores), stream, true);
+}
+
+extern "C" int sa_hip_widen16(const int16_t *d_src, int32_t *d_dst, int64_t count, void *stream)
+{
+	if (count < 0 || (count && (!d_src || !d_dst))) {
+		sa_set_error("sa_hip_widen16: bad arguments");
+		return 1;
+	}
+	SA_HIP_CHECK(sa_launch_widen16(d_src, d_dst, count, (hipStream_t)stream), return 1);
+	return 0;
+}
+
+static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16)
 {
 	if (!ctx || start < 0 || count < 0 || start + count > ctx->pairs || (!d_scores && count)) {
 		sa_set_error("sa_ctx_align_range: bad range [%lld,+%lld) of %lld pairs", (long long)start,
@@ -702,6 +747,7 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.start = start;
 		a.end = start + count;
 		a.out = d_scores;
+		a.out16 = out16 ? 1 : 0;
 		a.pconst = ctx->sys_pconst;
 		a.q = ctx->sys_q;
 		a.gap_g = ctx->sc.gap_pen;
@@ -777,7 +823,9 @@ extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int
 		a.gap_ext = ctx->sc.gap_ext;
 		a.start = run.first;
 		a.count = run.second;
-		a.out = d_scores + (run.first - start);
+		a.out = out16 ? reinterpret_cast<int32_t *>(reinterpret_cast<int16_t *>(d_scores) + (run.first - start))
+			      : d_scores + (run.first - start);
+		a.out16 = out16 ? 1 : 0;
 		a.scratch = ctx->d_scratch;
 		a.scratch_stride = ctx->scratch_stride;
 		const int blocks = (int)std::min<int64_t>(ctx->generic_blocks, (run.second + 3) / 4);

@@ -156,8 +156,12 @@ __global__ __launch_bounds__(256) void sa_k_pair_per_wave(SaGenericArgs A)
 			score = wave_max(best);
 		else
 			score = __shfl(h, (n - 1) & 63, 64); /* M[m][n] sits in the lane owning column n */
-		if (lane == 0)
-			A.out[q] = score;
+		if (lane == 0) {
+			if (A.out16)
+				reinterpret_cast<int16_t *>(A.out)[q] = (int16_t)score;
+			else
+				A.out[q] = score;
+		}
 	}
 }
 
@@ -204,6 +208,34 @@ const char *sa_generic_kernel_name(int method)
 {
 	static const char *names[] = { "sa_k_pair_per_wave<nw>", "sa_k_pair_per_wave<ga>", "sa_k_pair_per_wave<sw>" };
 	return (method >= 0 && method < 3) ? names[method] : "?";
+}
+
+/* int16 exchange format back to the reference's s32 (sign extension), 8 scores per thread and pass */
+__global__ __launch_bounds__(256) void sa_k_widen16(const int16_t *__restrict__ src, int32_t *__restrict__ dst, int64_t count,
+						     int64_t nvec /* 16-byte groups (0 when a pointer is not 16-byte aligned) */)
+{
+	const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+	for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += stride) {
+		const uint4 w = reinterpret_cast<const uint4 *>(src)[v];
+		int4 lo, hi;
+		lo.x = (int16_t)(w.x & 0xffffu), lo.y = (int16_t)(w.x >> 16), lo.z = (int16_t)(w.y & 0xffffu), lo.w = (int16_t)(w.y >> 16);
+		hi.x = (int16_t)(w.z & 0xffffu), hi.y = (int16_t)(w.z >> 16), hi.z = (int16_t)(w.w & 0xffffu), hi.w = (int16_t)(w.w >> 16);
+		reinterpret_cast<int4 *>(dst)[2 * v] = lo;
+		reinterpret_cast<int4 *>(dst)[2 * v + 1] = hi;
+	}
+	for (int64_t k = (nvec << 3) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride)
+		dst[k] = src[k];
+}
+
+hipError_t sa_launch_widen16(const int16_t *src, int32_t *dst, int64_t count, hipStream_t s)
+{
+	if (count <= 0)
+		return hipSuccess;
+	int64_t blocks = ((count >> 3) + 255) / 256;
+	blocks = blocks < 1 ? 1 : blocks > 256 * 16 ? 256 * 16 : blocks;
+	const bool aligned = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+	hipLaunchKernelGGL(sa_k_widen16, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, count, aligned ? count >> 3 : (int64_t)0);
+	return hipGetLastError();
 }
 
 hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t num, hipStream_t s)

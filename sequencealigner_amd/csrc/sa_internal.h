@@ -38,6 +38,7 @@ struct SaGenericArgs {
 	int32_t gap_pen, gap_opn, gap_ext;
 	int64_t start, count;         /* packed pair range                                      */
 	int32_t *out;                 /* out[q] = score of pair start+q                         */
+	int32_t out16;                /* != 0: out is an int16_t array (exchange format)        */
 	int32_t *scratch;             /* per-wave strip boundary columns (M and X)              */
 	int64_t scratch_stride;       /* ints per wave = 2*(max_len+2)                          */
 };
@@ -84,6 +85,7 @@ struct SaSysArgs {
 	int32_t ncols, num;
 	int64_t start, end;      /* packed pair range [start, end) being computed                         */
 	int32_t *out;            /* out[p - start]                                                        */
+	int32_t out16;           /* != 0: out is an int16_t array (scores proven to fit; exchange format) */
 	int32_t pconst;          /* constant folded into the profile: NW -2g, GA -e-o, SW -o              */
 	int32_t q;               /* GA: o - e (<= 0); else 0                                              */
 	int32_t gap_g, gap_o, gap_e;
@@ -109,5 +111,6 @@ hipError_t sa_launch_filter_relation(const uint8_t *codes, const int32_t *off, i
 				      unsigned long long *rel, int32_t jt0, int32_t tile_rows, hipStream_t s);
 
 hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t num, hipStream_t s);
+hipError_t sa_launch_widen16(const int16_t *src, int32_t *dst, int64_t count, hipStream_t s);
 
 #endif /* SA_INTERNAL_H */

@@ -243,3 +243,34 @@ def test_baseline_full_size_cfg4_cfg5(cfg_name, sa, oracle, torch_cuda):
         else:
             g = -scoring.gap_pen
             assert hi <= smax * int(lens.max()) and lo >= -g * 2 * int(lens.max()) + int(scoring.sub.min()) * int(lens.max())
+
+
+def test_int16_exchange_format(sa, oracle, torch_cuda):
+    """sa_ctx_align_range16 + sa_hip_widen16 == sa_ctx_align_range when the score bound fits int16; refused otherwise"""
+    torch = torch_cuda
+    store = sa.SequenceStore.from_sequences(make_protein_set(500, 30, 260, 31))
+    st = torch.cuda.current_stream().cuda_stream
+    for method, gaps in (("nw", dict(gap_pen=4)), ("ga", dict(gap_open=10, gap_extend=1)), ("sw", dict(gap_open=10, gap_extend=1))):
+        scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+        want = oracle.align(store, scoring, triangular=True)
+        with sa.Context(store, scoring, 0) as ctx:
+            assert ctx.scores_fit16
+            a, b = 12345, ctx.pairs - 777          # a range that starts and ends inside columns, odd offsets
+            out16 = torch.full((b - a + 3,), -7, dtype=torch.int16, device="cuda")
+            ctx.align_range16(a, b - a, out16[3:].data_ptr(), st)   # deliberately not 16-byte aligned
+            out32 = torch.empty(b - a, dtype=torch.int32, device="cuda")
+            ctx.widen16(out16[3:].data_ptr(), out32.data_ptr(), b - a, st)
+            torch.cuda.synchronize()
+            assert np.array_equal(out32.cpu().numpy(), want[a:b])
+            assert int(out16[0]) == -7 and int(out16[2]) == -7
+            al16 = torch.empty(b - a, dtype=torch.int16, device="cuda")      # aligned: the vector path of the widening
+            ctx.align_range16(a, b - a, al16.data_ptr(), st)
+            ctx.widen16(al16.data_ptr(), out32.data_ptr(), b - a, st)
+            torch.cuda.synchronize()
+            assert np.array_equal(out32.cpu().numpy(), want[a:b])
+    big = sa.SequenceStore.from_sequences(make_protein_set(20, 1500, 2500, 32))
+    with sa.Context(big, sa.Scoring.from_names("nw", "blosum62", gap_pen=4), 0) as ctx:
+        assert not ctx.scores_fit16          # 2500 * 11 + 2 * 2500 * 4 > 32767
+        buf = torch.empty(ctx.pairs, dtype=torch.int16, device="cuda")
+        with pytest.raises(sa.AlignError):
+            ctx.align_range16(0, ctx.pairs, buf.data_ptr(), st)
