@@ -43,6 +43,18 @@ for c in range(sched.chunks):
 for w in works:
     w.wait()
 assert np.array_equal(buf[:store.pairs].numpy(), full), f"rank {rank}: chunked gather differs"
+# the int16 exchange format of bench.py: slices gathered as bytes (uint8 views), then widened
+buf16 = torch.zeros(sched.total, dtype=torch.int16)
+works = []
+for c in range(sched.chunks):
+    lo, hi = sched.slice_range(c)
+    if hi > lo:
+        sched.my_slice(buf16, c)[:hi - lo] = torch.from_numpy(o.align_range(store, scoring, lo, hi - lo, threads=2).astype(np.int16))
+    works.append(dist.all_gather_into_tensor(sched.super_chunk(buf16, c).view(torch.uint8),
+                                             sched.my_slice(buf16, c).clone().view(torch.uint8), async_op=True))
+for w in works:
+    w.wait()
+assert np.array_equal(buf16[:store.pairs].to(torch.int32).numpy(), full), f"rank {rank}: int16 exchange differs"
 # work-balanced cut points (the general driver's rule) cover the index exactly once
 b = store.partition(world)
 assert b[0] == 0 and b[-1] == store.pairs
