@@ -5,6 +5,8 @@
     symmetry of the expanded matrix, row-permutation consistency).
 Bar: bit-exact (s32)."""
 import numpy as np
+import os
+
 import pytest
 
 from tests.golden_util import golden_cases, load_case, tri_to_full
@@ -268,6 +270,18 @@ def test_int16_exchange_format(sa, oracle, torch_cuda):
             ctx.widen16(al16.data_ptr(), out32.data_ptr(), b - a, st)
             torch.cuda.synchronize()
             assert np.array_equal(out32.cpu().numpy(), want[a:b])
+    os.environ["SA_HIP_FORCE_GENERIC"] = "1"      # the always-applicable kernels honour the exchange format too
+    try:
+        scoring = sa.Scoring.from_names("ga", "blosum62", gap_open=10, gap_extend=1)
+        small = store.prefix(120)
+        want = oracle.align(small, scoring, triangular=True)
+        with sa.Context(small, scoring, 0) as ctx:
+            o16 = torch.empty(ctx.pairs, dtype=torch.int16, device="cuda")
+            ctx.align_range16(0, ctx.pairs, o16.data_ptr(), st)
+            torch.cuda.synchronize()
+            assert np.array_equal(o16.cpu().numpy().astype(np.int32), want)
+    finally:
+        del os.environ["SA_HIP_FORCE_GENERIC"]
     big = sa.SequenceStore.from_sequences(make_protein_set(20, 1500, 2500, 32))
     with sa.Context(big, sa.Scoring.from_names("nw", "blosum62", gap_pen=4), 0) as ctx:
         assert not ctx.scores_fit16          # 2500 * 11 + 2 * 2500 * 4 > 32767
