@@ -42,6 +42,7 @@ struct sa_ctx {
 	enum { COUNTER_SLOTS = 256, COUNTERS_PER_SLOT = SA_SYS_NCLASSES + 1 };
 	unsigned *d_counters = nullptr;
 	uint64_t call_no = 0;
+	hipEvent_t slot_done[COUNTER_SLOTS] = {}; /* recorded after the launches that used a slot: its next user waits */
 	int32_t *d_long_scratch = nullptr; /* strip boundaries of the strip-mined launch, per workgroup   */
 	int64_t long_stride = 0;           /* ints per workgroup                                          */
 	int long_wgs = 0;
@@ -378,6 +379,9 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 	(void)hipFree(ctx->d_sub8);
 	(void)hipFree(ctx->d_scratch);
 	(void)hipFree(ctx->d_counters);
+	for (hipEvent_t ev : ctx->slot_done)
+		if (ev)
+			(void)hipEventDestroy(ev);
 	(void)hipFree(ctx->d_long_scratch);
 	for (int k = 0; k < sa_ctx::NSIDE; k++) {
 		if (ctx->side[k])
@@ -718,7 +722,13 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 	/* systolic streaming kernels: one persistent launch per column-length class; with several classes the
 	 * launches go to side streams forked from / joined back into the caller's stream so they run concurrently */
 	const bool fan_out = ctx->plan->classes.size() > 1 && !getenv("SA_HIP_SERIAL_CLASSES");
-	unsigned *const counters = ctx->d_counters + (ctx->call_no++ % sa_ctx::COUNTER_SLOTS) * sa_ctx::COUNTERS_PER_SLOT;
+	const size_t slot = (size_t)(ctx->call_no++ % sa_ctx::COUNTER_SLOTS);
+	unsigned *const counters = ctx->d_counters + slot * sa_ctx::COUNTERS_PER_SLOT;
+	if (ctx->slot_done[slot]) { /* 256 calls ago, possibly on another stream: normally long complete */
+		SA_HIP_CHECK(hipStreamWaitEvent(s, ctx->slot_done[slot], 0), return 1);
+	} else {
+		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->slot_done[slot], hipEventDisableTiming), return 1);
+	}
 	if (!ctx->plan->classes.empty()) {
 		SA_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(unsigned) * sa_ctx::COUNTERS_PER_SLOT, s), return 1);
 	}
@@ -810,6 +820,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		}
 	}
 	s = caller;
+	SA_HIP_CHECK(hipEventRecord(ctx->slot_done[slot], s), return 1);
 
 	/* everything the fast path does not cover: pair-per-wave kernels on contiguous packed runs */
 	for (const auto &run : ctx->plan->generic) {
