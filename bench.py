@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- all-vs-all alignment throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 5 --warmup 1
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8            (spawns torch.distributed.run itself, one rank per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is ONE pass of the hot path over the whole workload: every pair i<j of the synthetic
-sequence set is scored (NW/BLOSUM62/gap 4 for the headline config) into the packed
-upper-triangular vector resident in HBM.  With N>1 ranks the packed pair index is cut into N
-contiguous ranges (strong scaling: total work fixed), every rank scores its range, and ONE RCCL
-all-gather over xGMI assembles the full vector on every GPU -- that all-gather is inside the timed
-step.  Inputs are resident in HBM before the timed region.
+A "step" is ONE pass of the hot path over the whole workload, inputs resident in HBM, results delivered to host
+memory -- the phase the reference's metric divides by (`pairs / alignment-phase seconds`, util/benchmark.c:63; the
+phase brackets the launch/copy loop INCLUDING the device->host copies, interface/seqalign_cuda.c:182,292):
+  N = 1   sa_ctx_align_host: every pair i<j scored (NW/BLOSUM62/gap 4 for the headline config) and the packed
+          upper-triangular s32 vector copied into a page-locked host matrix, copies overlapping the kernels.
+  N > 1   the packed index is cut into N contiguous ranges per super-chunk (strong scaling: total work fixed);
+          every rank scores its ranges, RCCL all-gathers over xGMI assemble the packed vector on every GPU, and
+          every rank copies its 1/N share of the finished vector to its page-locked host buffer -- all inside the
+          timed step (sequencealigner_amd/distributed.py: GatherStep).
 
 Printed JSON (rank 0): metric/value per the driver contract, plus
-  roofline     -- dominant kernel vs the HBM roof, live HIP-event timing on the launch stream
-  cpu_baseline -- the reference's own CPU path (oracle/_ref, kind "reference") or our C restatement
-                  (oracle/, kind "port") timed on this host's cores on a bounded sample
-  gcups, valu  -- the bound that actually constrains this integer DP
+  device_resident -- the same pass with the result left in HBM (kernels only; >= value)
+  host_boundary   -- sa_hip_align cold call (encode + upload + loop) and the `seqalign` CLI FASTA->HDF5 with -B
+  roofline        -- dominant kernel vs the HBM roof, live HIP-event timing on the launch stream
+  cpu_baseline    -- the reference's own CPU path (oracle/_ref, kind "reference") or our C restatement
+                     (oracle/, kind "port") timed on this host's cores on a bounded sample
+  gcups, valu     -- the bound that actually constrains this integer DP
+  extra.configs   -- cfg3 (Gotoh, full size) and the cfg4 shape (SW nuc44, one GPU's worth) measured the same way
 """
 from __future__ import annotations
 
@@ -24,45 +31,65 @@ import argparse
 import json
 import os
 import pathlib
+import re
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = pathlib.Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-import sequencealigner_amd as sa  # noqa: E402
-from sequencealigner_amd.distributed import ChunkedGather  # noqa: E402
-from tests.synth import CONFIGS, make_config  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 s32 lane-ops/s
 OPS_PER_CELL = {"nw": 5, "ga": 9, "sw": 11}  # reference op counts (nw.c:29-35, ga.c:47-62, sw.c:39-57)
-# SIMD issue cycles one wave64 DP cell costs at the very least with this kernel's instruction selection, from the
-# measured per-opcode rates at 8 waves/SIMD (profiles/r01_microbench_valu_rates.txt, r01f_microbench_vgpr_banks.txt):
-# SDWA add / v_max3 2.3, v_max_i32 1.77, v_add_u32 1.1   -> nw 2 ops, ga 5 ops, sw 9 ops per cell
-MIN_ISSUE_CYCLES_PER_CELL = {"nw": 2 * 2.3, "ga": 2 * 2.3 + 2 * 1.77 + 1.1, "sw": 2 * 2.3 + 4 * 1.77 + 3 * 1.1}
+# wave64 VALU instructions one DP cell costs at the very least with this kernel's formulation times
+# the guide's 2 SIMD cycles per wave64 instruction (MI355X_MICROARCH.md, v_fma_f32 row; calibration of the
+# microbenchmarks against wall clock: profiles/r02_microbench_valu_rates.txt)
+MIN_INSTS_PER_CELL = {"nw": 2, "ga": 5, "sw": 6.5}
+CYCLES_PER_WAVE64_INST = 2.0
 SIMDS, SHADER_HZ = 256 * 4, 2.4e9
+CFG4_SHAPE_N = 12_000  # "cfg4 shape": the cfg4 generator and scoring at a size one GPU finishes in a fraction of a second
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2")
     ap.add_argument("--n", "--nseq", dest="n", type=int, default=None, help="override sequence count (parity/debug runs)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-boundary", action="store_true", help="skip the untimed sa_hip_align end-to-end check (profiling runs)")
+    ap.add_argument("--no-host-boundary", action="store_true", help="skip the sa_hip_align / CLI end-to-end legs (profiling runs)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs legs (cfg3, cfg4 shape)")
+    ap.add_argument("--device-resident-only", action="store_true", help="time the kernels only (result stays in HBM): profiling runs")
     ap.add_argument("--chunks", type=int, default=None, help="super-chunks per step for compute/all-gather overlap (N>1; default: pick 1, 2 or 4 by an untimed trial)")
     return ap.parse_args()
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU with torch.distributed.run as a CHILD
+    process (nothing in this process has touched the GPU) and relay its output and exit code."""
+    import torch
+    have = torch.cuda.device_count()  # does not initialise the runtime on this image
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this box has {have}; "
+              f"one rank per GPU over RCCL cannot be started (run with --gpus {max(have, 1)})", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
 def cpu_baseline(seqs, cfg, target_s: float) -> dict:
     """Reference CPU path on a bounded prefix of the same workload (pairs/s, all host cores)."""
+    import sequencealigner_amd as sa
     from tests.oracle_binding import Oracle, RefLib, ref_available
 
     ncores = os.cpu_count() or 1
@@ -105,75 +132,163 @@ def cpu_baseline(seqs, cfg, target_s: float) -> dict:
     }
 
 
+def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_size: bool) -> dict:
+    """dominant kernel: algorithmic HBM bytes of ONE launch (4 B per pair written + the sequence store
+    and its offsets read once) / that kernel's average launch duration (HIP events on the launch stream)"""
+    launches = max(tm["launches"], 1)
+    k_pairs = tm["pairs"] // launches
+    alg_bytes = 4 * k_pairs + int(store.blob.size) + 8 * store.num
+    avg_ms = tm["ms"] / launches
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM traffic of that kernel per launch from the committed PMC passes (profiles/*_traffic.json), if the workload,
+    # launch size and kernel match; null otherwise (it cannot be measured inside this process)
+    traffic = None
+    for tf in sorted((ROOT / "profiles").glob("*_traffic.json")):
+        tj = json.loads(tf.read_text())
+        if (tj.get("kernel") == tm["kernel"] and tj.get("workload") == workload and world == 1 and full_size
+                and abs(tj.get("pairs_per_launch", k_pairs) - k_pairs) <= 0.02 * k_pairs):
+            traffic = tj["traffic_bytes_per_launch"]
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": tm["kernel"], "kernel_avg_ms": avg_ms, "launches": tm["launches"],
+            "algorithmic_bytes_per_launch": alg_bytes, "pairs_per_launch": k_pairs,
+            "sum_of_kernel_ms_per_step": tm["all_kernels_ms"] / steps,
+            "note": "per-class kernels of one range overlap on side streams; durations are per launch as rocprofv3 reports them"}
+
+
+def valu_of(method: str, cells: int, seconds: float) -> dict:
+    gcups = cells / seconds / 1e9
+    return {"gcups_this_rank": gcups, "reference_ops_per_cell": OPS_PER_CELL[method],
+            "min_wave64_insts_per_cell": MIN_INSTS_PER_CELL[method], "cycles_per_wave64_inst": CYCLES_PER_WAVE64_INST,
+            # wave-cells x (minimal instructions per cell x 2 cycles) / SIMD cycles available in the step
+            "frac_of_valu_issue_bound": (cells / 64) * MIN_INSTS_PER_CELL[method] * CYCLES_PER_WAVE64_INST / (seconds * SIMDS * SHADER_HZ)}
+
+
+def time_host_steps(ctx, dest, steps: int, warmup: int, torch) -> tuple[float, dict]:
+    """steps x sa_ctx_align_host (launch + device->host copy loop into the page-locked packed matrix)"""
+    for _ in range(warmup):
+        ctx.align_host(dest.array, triangular=True)
+    torch.cuda.synchronize()
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.align_host(dest.array, triangular=True)  # returns when the last copy has landed
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tm = ctx.timing_read()
+    ctx.timing(False)
+    return elapsed, tm
+
+
+def time_resident_steps(ctx, packed, pairs: int, steps: int, warmup: int, torch) -> tuple[float, dict]:
+    s = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        ctx.align_range(0, pairs, packed.data_ptr(), s)
+    torch.cuda.synchronize()
+    ctx.timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.align_range(0, pairs, packed.data_ptr(), s)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tm = ctx.timing_read()
+    ctx.timing(False)
+    return elapsed, tm
+
+
+def cli_leg(seqs, cfg) -> dict | None:
+    """The product as a user runs it: `cli/seqalign -i x.fasta -o x.h5 ... -B` from a cold process."""
+    exe = ROOT / "cli" / "seqalign"
+    if not exe.exists():
+        return None
+    with tempfile.TemporaryDirectory(prefix="sa_bench_") as tmp:
+        fasta = pathlib.Path(tmp) / "in.fasta"
+        with open(fasta, "wb") as f:
+            for k, s in enumerate(seqs):
+                f.write(b">s%d\n" % k + s + b"\n")
+        g = cfg["gaps"]
+        gaps = ["-p", str(g["gap_pen"])] if "gap_pen" in g else ["-s", str(g["gap_open"]), "-e", str(g["gap_extend"])]
+        cmd = [str(exe), "-i", str(fasta), "-o", str(pathlib.Path(tmp) / "out.h5"), "-a", cfg["method"], "-m", cfg["matrix"], *gaps, "-B", "-F", "-Q"]
+        t0 = time.perf_counter()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        wall = time.perf_counter() - t0
+    txt = r.stdout + r.stderr
+    if r.returncode != 0:
+        return {"error": txt[-400:], "returncode": r.returncode}
+
+    def grab(label):
+        m = re.search(label + r":\s*([0-9.]+)", txt)
+        return float(m.group(1)) if m else None
+    return {"command": " ".join(["cli/seqalign", *cmd[1:2], "in.fasta", "-o", "out.h5", *cmd[5:]]),
+            "alignments_per_second": grab("Alignments per second"), "input_s": grab("Input"), "filter_s": grab("Filter"),
+            "alignment_s": grab("Alignment"), "output_s": grab("Output"), "setup_s": grab(r"outside the phases as in the reference"),
+            "process_wall_s": wall,
+            "note": "cold process, FASTA -> full N x N HDF5; alignment = the launch/copy loop (reference's bench_align bracket), "
+                    "setup = context, code-object load, upload, buffers and page-locking (outside the phases as in the reference)"}
+
+
+def extra_config(name: str, n, steps: int, cpu_seconds: float, torch, sa, make_config) -> dict:
+    """cfg3 / cfg4-shape leg: the same measurement as the headline, a few steps, in this process"""
+    seqs, cfg = make_config(name, n)
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    pairs, cells = store.pairs, store.cells()
+    ctx = sa.Context(store, scoring, 0)
+    dest = sa.PinnedMatrix(pairs)
+    try:
+        elapsed, tm = time_host_steps(ctx, dest, steps, 1, torch)
+        packed = torch.empty(pairs, dtype=torch.int32, device="cuda")
+        el_res, _ = time_resident_steps(ctx, packed, pairs, steps, 1, torch)
+        same = bool((torch.from_numpy(dest.array).cuda() == packed).all().item())
+        del packed
+    finally:
+        ctx.close()
+        dest.close()
+    sec = elapsed / steps
+    out = {"workload": f"{name}{'' if n is None else ' shape'}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], {cfg['method']} {cfg['matrix']} {cfg['gaps']}",
+           "pairs": pairs, "cells": cells, "steps": steps, "ms_per_step": sec * 1e3, "value": pairs / sec, "unit": "pair-alignments/s",
+           "gcups": cells / sec / 1e9,
+           "device_resident": {"ms_per_step": el_res / steps * 1e3, "value": pairs * steps / el_res, "gcups": cells * steps / el_res / 1e9},
+           "host_result_equals_device_result": same,
+           "roofline": roofline_of(tm, store, steps, name, 1, n is None), "valu": valu_of(cfg["method"], cells, sec)}
+    out["cpu_baseline"] = cpu_baseline(seqs, cfg, cpu_seconds) if cpu_seconds > 0 else None
+    return out
+
+
 def main():
     args = parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not os.environ.get("SA_BENCH_FORCE_DIST"):
+        raise SystemExit(self_launch(args))
+
+    import numpy as np
+    import torch
+    import sequencealigner_amd as sa
+    from sequencealigner_amd.distributed import GatherStep
+    from tests.synth import CONFIGS, make_config
+
+    if args.config not in CONFIGS:
+        raise SystemExit(f"unknown --config {args.config}; one of {sorted(CONFIGS)}")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("SA_BENCH_FORCE_DIST"):  # the env switch rehearses the RCCL path on one GPU
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:  # 1-rank rehearsal without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29517"), RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     seqs, cfg = make_config(args.config, args.n)
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    method = scoring.method_name
     pairs = store.pairs
     cells = store.cells()
-
-    # strong scaling: total work fixed.  The packed index is cut chunk-major / rank-minor (ChunkedGather) so that
-    # the all-gather of super-chunk c overlaps the kernels of super-chunk c+1 and lands in place in packed order.
     use_dist = dist is not None
     ctx = sa.Context(store, scoring, local_rank)
-    main = torch.cuda.current_stream()
-    comm = torch.cuda.Stream() if use_dist else None
-    side = []
-
-    # exchange format of the all-gather: int16 when every score of this workload provably fits (half the bytes over
-    # xGMI); the gathered vector is widened to the reference's s32 on every GPU inside the timed step
-    use16 = use_dist and ctx.scores_fit16 and not os.environ.get("SA_BENCH_GATHER32")
-
-    def schedule(chunks):
-        """(sched, step) for `chunks` super-chunks per step; one compute stream per super-chunk, so the kernels of
-        consecutive super-chunks may overlap while the gather of each starts as soon as its own kernels finish."""
-        sched = ChunkedGather(pairs, world, rank, chunks)
-        while use_dist and len(side) < chunks:
-            side.append(torch.cuda.Stream())
-        streams = side[:chunks] if use_dist else [main]
-
-        def step():
-            works = []
-            if use_dist:
-                start = torch.cuda.Event()
-                start.record(main)
-            for c in range(sched.chunks):
-                lo, hi = sched.slice_range(c)
-                cs = streams[c]
-                if use_dist:
-                    cs.wait_event(start)  # ordered after the previous step
-                buf = packed16 if use16 else packed
-                if use16:
-                    ctx.align_range16(lo, hi - lo, sched.my_slice(buf, c).data_ptr(), cs.cuda_stream)
-                else:
-                    ctx.align_range(lo, hi - lo, sched.my_slice(buf, c).data_ptr(), cs.cuda_stream)
-                if use_dist:
-                    done = torch.cuda.Event()
-                    done.record(cs)
-                    with torch.cuda.stream(comm):
-                        comm.wait_event(done)
-                        # (the process group moves bytes; int16 is not among its dtypes, uint8 is)
-                        works.append(dist.all_gather_into_tensor(sched.super_chunk(buf, c).view(torch.uint8),
-                                                                 sched.my_slice(buf, c).view(torch.uint8), async_op=True))
-            for w in works:
-                w.wait()  # the main stream waits for the gathers (and therefore the kernels) of this step
-            if use16:
-                ctx.widen16(packed16.data_ptr(), packed.data_ptr(), sched.total, main.cuda_stream)
-        return sched, step
+    out = None
 
     def fence():
         torch.cuda.synchronize()
@@ -181,18 +296,75 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    workload = (f"{args.config}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], "
+                f"{cfg['method']} {cfg['matrix']} {cfg['gaps']}, all-vs-all packed triangular")
+    if not use_dist:
+        # ---- N = 1: the reference's phase = launch + device->host copy loop, page-locked destination ----
+        packed = torch.empty(pairs, dtype=torch.int32, device="cuda")
+        el_res, tm_res = time_resident_steps(ctx, packed, pairs, args.steps, args.warmup, torch)
+        if args.device_resident_only:
+            elapsed, tm, dest = el_res, tm_res, None
+        else:
+            dest = sa.PinnedMatrix(pairs)
+            elapsed, tm = time_host_steps(ctx, dest, args.steps, args.warmup, torch)
+            assert np.array_equal(dest.array, packed.cpu().numpy()), "host-delivered result differs from device-resident result"
+        sec = elapsed / args.steps
+        out = {
+            "metric": "pair-alignments/sec", "value": pairs / sec, "unit": "pair-alignments/s",
+            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32", "data": "synthetic",
+            "config": {"workload": workload, "pairs": pairs, "cells": cells, "parallelism": "pair-range x1",
+                       "timed_region": ("kernels only, result left in HBM (--device-resident-only)" if args.device_resident_only else
+                                        "sa_ctx_align_host: launch + device->host copy loop into a page-locked packed host matrix "
+                                        "(the reference's bench_align bracket, seqalign_cuda.c:182,292); inputs resident in HBM")},
+            "gcups": cells / sec / 1e9,
+            "device_resident": {"value": pairs * args.steps / el_res, "ms_per_step": el_res / args.steps * 1e3,
+                                "gcups": cells * args.steps / el_res / 1e9,
+                                "note": "same pass, result left in HBM (kernels only); round-1 headline definition"},
+            "roofline": roofline_of(tm, store, args.steps, args.config, 1, args.n is None),
+            "valu": valu_of(method, cells, sec),
+            "device": sa.device_name(local_rank),
+        }
+        if not args.no_host_boundary:
+            t1 = time.perf_counter()
+            host = sa.hip_align(store, scoring, triangular=True)
+            e2e = time.perf_counter() - t1
+            e2e_phase = sa.last_align_seconds()
+            assert np.array_equal(host, packed.cpu().numpy()), "host-boundary result differs from device-resident result"
+            del host
+            out["host_boundary"] = {
+                "seconds": e2e, "pairs_per_s": pairs / e2e, "align_phase_seconds": e2e_phase,
+                "align_phase_pairs_per_s": pairs / e2e_phase if e2e_phase > 0 else None,
+                "note": "one sa_hip_align call on a pageable destination: encode + context + upload + page-locking + loop; "
+                        "align_phase = its launch/copy loop only",
+                "cli": cli_leg(seqs, cfg)}
+        del packed
+        if dest is not None:
+            dest.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(seqs, cfg, args.cpu_seconds)
+        ctx.close()
+        if not args.no_extra and args.config == "cfg2" and args.n is None and not args.device_resident_only:
+            cpu_s = 0.0 if args.no_cpu_baseline else max(3.0, args.cpu_seconds / 2)
+            extra = {}
+            for key, (name, n) in {"cfg3": ("cfg3", None), "cfg4": ("cfg4", CFG4_SHAPE_N)}.items():
+                extra[key] = extra_config(name, n, 3, cpu_s, torch, sa, make_config)
+            out["extra"] = {"configs": extra}
+        print(json.dumps(out), flush=True)
+        return
+
+    # ---- N > 1 (or the 1-rank RCCL rehearsal): slices + overlapped all-gathers + per-rank host delivery ----
+    # exchange format of the all-gather: int16 when every score of this workload provably fits (half the bytes over
+    # xGMI); the gathered vector is widened to the reference's s32 on every GPU inside the timed step
+    use16 = ctx.scores_fit16 and not os.environ.get("SA_BENCH_GATHER32")
     # super-chunks per step: more of them hide more of the all-gather behind the kernels but shorten the kernels'
     # row streams; the trade depends on the fabric, so (unless --chunks fixes it) it is measured before the warmup,
     # untimed, and every rank takes the same decision from the max-over-ranks time
-    candidates = [args.chunks] if (args.chunks or not use_dist) else [1, 2, 4]
-    if not use_dist:
-        candidates = [1]
-    packed = torch.zeros(max(ChunkedGather(pairs, world, rank, c).total for c in candidates), dtype=torch.int32, device="cuda")
-    packed16 = torch.zeros(packed.numel(), dtype=torch.int16, device="cuda") if use16 else None
+    candidates = [args.chunks] if args.chunks else [1, 2, 4]
     tuned = {}
     if len(candidates) > 1:
         for c in candidates:
-            _, trial = schedule(c)
+            trial = GatherStep(ctx, pairs, world, rank, c, dist, use16)
             trial(); trial()
             fence()
             t0 = time.perf_counter()
@@ -202,9 +374,10 @@ def main():
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tuned[c] = float(t.item()) / 4 * 1e3
+            del trial
         candidates = [min(tuned, key=tuned.get)]
-    sched, step = schedule(candidates[0])
-    my_pairs = sum(hi - lo for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
+    step = GatherStep(ctx, pairs, world, rank, candidates[0], dist, use16)
+    sched = step.sched
     my_cells = sum(store.cells(lo, hi - lo) for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
 
     for _ in range(args.warmup):
@@ -218,101 +391,52 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = ctx.timing_read()
     ctx.timing(False)
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # N>1: every rank re-scores a few random windows of the gathered vector with its own kernels (untimed) and
-    # compares -- the gathered result of the last step must be the packed matrix in natural order on every GPU
-    gather_ok = None
-    if use_dist:
-        vrng = np.random.default_rng(1234 + rank)
-        okflag = 1
-        for _ in range(6):
-            w = int(min(pairs, 65536))
-            a0 = int(vrng.integers(0, pairs - w + 1))
-            chk = torch.empty(w, dtype=torch.int32, device="cuda")
-            ctx.align_range(a0, w, chk.data_ptr(), main.cuda_stream)
-            torch.cuda.synchronize()
-            if not torch.equal(chk, packed[a0:a0 + w]):
-                okflag = 0
-        t = torch.tensor([okflag], dtype=torch.int32, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        gather_ok = bool(t.item())
-
-    # end-to-end through the host boundary (upload + kernels + D2H of the packed result), rank 0, N=1 only
-    e2e = None
-    if world == 1 and not args.no_host_boundary:
-        t1 = time.perf_counter()
-        host = sa.hip_align(store, scoring, triangular=True)
-        e2e = time.perf_counter() - t1
-        e2e_phase = sa.last_align_seconds()
-        assert np.array_equal(host, packed[:pairs].cpu().numpy()), "host-boundary result differs from device-resident result"
+    # every rank re-scores a few random windows of the gathered vector with its own kernels (untimed) and compares, and
+    # checks its host share against the gathered vector: the result of the last step must be the packed matrix in
+    # natural order on every GPU and on the host.  (The oracle-backed check of this schedule: tests/test_gpu_gather_step.py)
+    vrng = np.random.default_rng(1234 + rank)
+    okflag = 1
+    for _ in range(6):
+        w = int(min(pairs, 65536))
+        a0 = int(vrng.integers(0, pairs - w + 1))
+        chk = torch.empty(w, dtype=torch.int32, device="cuda")
+        ctx.align_range(a0, w, chk.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        if not torch.equal(chk, step.packed[a0:a0 + w]):
+            okflag = 0
+    for lo, hi, ho in step.host_ranges():
+        if not torch.equal(step.host[ho:ho + hi - lo], step.packed[lo:hi].cpu()):
+            okflag = 0
+    t = torch.tensor([okflag], dtype=torch.int32, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    gather_ok = bool(t.item())
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = pairs * args.steps / elapsed
-        # dominant kernel: algorithmic HBM bytes of ONE launch (4 B per pair written + the
-        # sequence store and its offsets read once) / that kernel's average launch duration (HIP events)
-        launches = max(tm["launches"], 1)
-        k_pairs = tm["pairs"] // launches
-        k_cells = tm["cells"] // launches
-        alg_bytes = 4 * k_pairs + int(store.blob.size) + 8 * store.num
-        avg_ms = tm["ms"] / launches
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        # the class kernels of a range run concurrently (side streams), so a single kernel's duration includes time it
-        # shared the chip with its siblings; the VALU view therefore uses the whole step (all kernels, this rank)
-        kernel_gcups = my_cells / (elapsed / args.steps) / 1e9
-        kname = tm["kernel"]
-        # HBM traffic of that kernel per launch from the committed PMC passes (profiles/*_traffic.json), if the
-        # workload and kernel match; null otherwise (it cannot be measured inside this process)
-        traffic = None
-        for tf in sorted((ROOT / "profiles").glob("*_traffic.json")):
-            tj = json.loads(tf.read_text())
-            if tj.get("kernel") == kname and tj.get("workload") == args.config and world == 1 and args.n is None:
-                traffic = tj["traffic_bytes_per_launch"]
+        sec = elapsed / args.steps
         out = {
-            "metric": "pair-alignments/sec", "value": value, "unit": "pair-alignments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32",
-            "data": "synthetic",
-            "config": {"workload": f"{args.config}: {store.num} {cfg['kind']} seqs x U[{cfg['lo']},{cfg['hi']}], "
-                                   f"{cfg['method']} {cfg['matrix']} {cfg['gaps']}, all-vs-all packed triangular",
-                       "pairs": pairs, "cells": cells, "parallelism": f"pair-range x{world}" + (f" + RCCL all-gather ({'int16 exchange, widened to s32 on device' if use16 else 's32'}), {sched.chunks} overlapped super-chunks" if use_dist else ""),
+            "metric": "pair-alignments/sec", "value": pairs / sec, "unit": "pair-alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32", "data": "synthetic",
+            "config": {"workload": workload, "pairs": pairs, "cells": cells,
+                       "parallelism": f"pair-range x{world} + RCCL all-gather ({'int16 exchange, widened to s32 on device' if use16 else 's32'}), "
+                                      f"{sched.chunks} overlapped super-chunks, every rank copies its 1/{world} share to page-locked host memory",
+                       "timed_region": "kernels + all-gathers + widen + per-rank device->host copies (GatherStep); inputs resident in HBM",
                        **({"super_chunk_trial_ms": tuned} if tuned else {}),
-                       **({"gathered_result_verified_on_every_rank": gather_ok} if gather_ok is not None else {})},
-            "gcups": cells * args.steps / elapsed / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
-                         "kernel_avg_ms": avg_ms, "launches": tm["launches"], "algorithmic_bytes_per_launch": alg_bytes,
-                         "pairs_per_launch": k_pairs, "sum_of_kernel_ms_per_step": tm["all_kernels_ms"] / args.steps,
-                         "note": "per-class kernels of one range overlap on side streams; durations are per launch as rocprofv3 reports them"},
-            "valu": {"gcups_this_rank": kernel_gcups, "reference_ops_per_cell": OPS_PER_CELL[scoring.method_name],
-                     "peak_lane_ops_per_s": VALU_LANE_OPS,
-                     "frac_of_valu_peak_at_reference_op_count": kernel_gcups * 1e9 * OPS_PER_CELL[scoring.method_name] / VALU_LANE_OPS,
-                     # the bound that actually applies: wave-cells x minimal issue cycles per cell / SIMD cycles available
-                     "min_issue_cycles_per_wave_cell": MIN_ISSUE_CYCLES_PER_CELL[scoring.method_name],
-                     "frac_of_valu_issue_bound": (my_cells / 64) * MIN_ISSUE_CYCLES_PER_CELL[scoring.method_name]
-                                                 / ((elapsed / args.steps) * SIMDS * SHADER_HZ)},
+                       "gathered_and_host_result_verified_on_every_rank": gather_ok},
+            "gcups": cells / sec / 1e9,
+            "roofline": roofline_of(tm, store, args.steps, args.config, world, args.n is None),
+            "valu": valu_of(method, my_cells, sec),
             "device": sa.device_name(local_rank),
+            "cpu_baseline": None,
         }
-        if e2e is not None:
-            out["host_boundary"] = {"seconds": e2e, "pairs_per_s": pairs / e2e,
-                                    "align_phase_seconds": e2e_phase, "align_phase_pairs_per_s": pairs / e2e_phase if e2e_phase > 0 else None,
-                                    "note": "sa_hip_align: encode+upload+kernels+D2H into pageable host memory (PCIe-inclusive); "
-                                            "align_phase = its launch/copy loop only, the phase the reference times (SURVEY 8d)"}
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(seqs, cfg, args.cpu_seconds)
-        elif not args.no_cpu_baseline:
-            out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":

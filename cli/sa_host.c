@@ -4,6 +4,7 @@
 
 #include <ctype.h>
 #include <errno.h>
+#include <fcntl.h>
 #include <limits.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -11,6 +12,8 @@
 #include <string.h>
 #include <strings.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -98,76 +101,90 @@ static int parse_fasta(uint8_t *file, const uint8_t *fend, const int32_t *lut, i
 	return 0;
 }
 
-/* ---- DSV (reference src/io/source/dsv.c:26-230) ------------------------------------------- */
-static const uint8_t *dsv_field(const uint8_t **cur, const uint8_t *end, uint8_t delim, int32_t *flen)
+/* ---- DSV (behaviour of reference src/io/source/dsv.c:26-230) --------------------------------
+ * Grammar:  record = field *( DELIM field ) EOL        EOL = CR | LF | end of input
+ *           field  = *( bare-char | quoted-run )       quoted-run = '"' *( char | '""' ) '"'
+ * A delimiter or line break inside a quoted run is data.  A field that begins and ends with a quote is
+ * delivered without that outer pair (inner "" stay as they are -- residues never contain quotes, and the
+ * header match is on whole names).  One scanner serves the header walk, the column count and the rows. */
+enum dsv_stop { DSV_AT_DELIM, DSV_AT_EOL };
+
+struct dsv_token {
+	const uint8_t *text;
+	int32_t len;
+	enum dsv_stop stop; /* what ended the field; the cursor is past a delimiter, ON a line break / the limit */
+};
+
+static struct dsv_token dsv_next(const uint8_t **cursor, const uint8_t *limit, uint8_t delim)
 {
-	const uint8_t *p = *cur, *start = p;
-	bool quoted = false;
-	while (p < end) {
-		if (*p == '"') {
-			if (quoted && p + 1 < end && p[1] == '"') {
-				p += 2;
+	enum { BARE, QUOTED, QUOTE_IN_QUOTED } state = BARE;
+	const uint8_t *const first = *cursor;
+	const uint8_t *p = first;
+	struct dsv_token tok = { first, 0, DSV_AT_EOL };
+	for (; p < limit; p++) {
+		const uint8_t ch = *p;
+		if (state == QUOTE_IN_QUOTED) { /* the quote before this byte: half of an escaped pair, or the closing one */
+			if (ch == '"') {
+				state = QUOTED;
 				continue;
 			}
-			quoted = !quoted;
-			p++;
+			state = BARE;
+		}
+		if (state == QUOTED) {
+			if (ch == '"')
+				state = QUOTE_IN_QUOTED;
 			continue;
 		}
-		if (!quoted && (*p == delim || *p == '\n' || *p == '\r'))
+		if (ch == '"') {
+			state = QUOTED;
+		} else if (ch == delim) {
+			tok.stop = DSV_AT_DELIM;
 			break;
-		p++;
+		} else if (ch == '\n' || ch == '\r') {
+			break;
+		}
 	}
-	int32_t len = (int32_t)(p - start);
-	if (len >= 2 && *start == '"' && start[len - 1] == '"') {
-		len -= 2;
-		start++;
+	tok.len = (int32_t)(p - first);
+	if (tok.len >= 2 && first[0] == '"' && first[tok.len - 1] == '"') {
+		tok.text = first + 1;
+		tok.len -= 2;
 	}
-	*flen = len;
-	if (p < end && *p == delim)
-		p++;
-	*cur = p;
-	return start;
+	*cursor = tok.stop == DSV_AT_DELIM ? p + 1 : p;
+	return tok;
 }
 
-static int32_t dsv_columns(const uint8_t *p, const uint8_t *end, uint8_t delim)
+static const uint8_t *dsv_skip_breaks(const uint8_t *p, const uint8_t *limit)
 {
-	int32_t count = 1;
-	bool quoted = false;
-	while (p < end) {
-		if (*p == '"') {
-			if (quoted && p + 1 < end && p[1] == '"') {
-				p += 2;
-				continue;
-			}
-			quoted = !quoted;
-		} else if (*p == delim && !quoted) {
-			count++;
-		}
-		if (!quoted && (*p == '\n' || *p == '\r'))
-			break;
+	while (p < limit && (*p == '\n' || *p == '\r'))
 		p++;
-	}
-	return count;
+	return p;
+}
+
+static bool dsv_is_sequence_header(const struct dsv_token *t)
+{
+	static const char *const NAMES[] = { "sequence", "seq", "protein", "dna", "rna", "amino", "peptide", "chain" };
+	for (size_t k = 0; k < sizeof(NAMES) / sizeof(NAMES[0]); k++)
+		if ((size_t)t->len == strlen(NAMES[k]) && !strncasecmp((const char *)t->text, NAMES[k], (size_t)t->len))
+			return true;
+	return false;
 }
 
 static int parse_dsv(uint8_t *file, const uint8_t *fend, uint8_t delim, const int32_t *lut, int32_t gap,
 		     int dsv_column, int dsv_has_header, struct builder *b)
 {
-	static const char *KEYS[] = { "sequence", "seq", "protein", "dna", "rna", "amino", "peptide", "chain", NULL };
+	/* first record: number of columns, and the first column whose name says "sequences" (dsv.c:21-24) */
 	const uint8_t *p = file;
-	const int32_t cols = dsv_columns(p, fend, delim);
-	int32_t seq_col = -1;
-	for (int32_t col = 0; col < cols; col++) {
-		int32_t flen;
-		const uint8_t *f = dsv_field(&p, fend, delim, &flen);
-		if (!flen)
+	int32_t cols = 0, seq_col = -1;
+	for (;;) {
+		const struct dsv_token t = dsv_next(&p, fend, delim);
+		if (!t.len)
 			return fail("First row has empty column");
-		for (const char **key = KEYS; *key && seq_col < 0; key++)
-			if ((size_t)flen == strlen(*key) && !strncasecmp((const char *)f, *key, (size_t)flen))
-				seq_col = col;
+		if (seq_col < 0 && dsv_is_sequence_header(&t))
+			seq_col = cols;
+		cols++;
+		if (t.stop != DSV_AT_DELIM)
+			break;
 	}
-	while (p < fend && (*p == '\n' || *p == '\r'))
-		p++;
 	if (seq_col < 0) {
 		/* the reference asks the user here (dsv.c:139-151) */
 		if (dsv_column < 0 || dsv_column >= cols)
@@ -175,31 +192,26 @@ static int parse_dsv(uint8_t *file, const uint8_t *fend, uint8_t delim, const in
 				    "peptide, chain); pass --column N [--no-header]");
 		seq_col = dsv_column;
 		if (!dsv_has_header)
-			p = file;
+			p = file; /* the first record is data */
 	}
-	while (p < fend) {
-		while (p < fend && (*p == '\n' || *p == '\r'))
-			p++;
-		if (p >= fend)
-			break;
+	for (p = dsv_skip_breaks(p, fend); p < fend; p = dsv_skip_breaks(p, fend)) {
 		const int32_t row = b->num + 1;
-		int32_t flen = 0;
-		for (int32_t col = 0; col < seq_col; col++) {
-			dsv_field(&p, fend, delim, &flen);
-			if (p >= fend || *p == '\n' || *p == '\r')
-				return fail("DSV row #%d has no sequence column", row);
+		struct dsv_token t = { NULL, 0, DSV_AT_DELIM };
+		int32_t col = 0;
+		for (; col < cols && t.stop == DSV_AT_DELIM; col++) {
+			t = dsv_next(&p, fend, delim);
+			if (col != seq_col)
+				continue;
+			if (!t.len)
+				return fail("Sequence #%d is empty", row);
+			if (add_sequence(b, t.text, (size_t)t.len, true, lut, gap, row))
+				return 1;
 		}
-		const uint8_t *f = dsv_field(&p, fend, delim, &flen);
-		if (!flen)
-			return fail("Sequence #%d is empty", row);
-		if (add_sequence(b, f, (size_t)flen, true, lut, gap, row))
-			return 1;
-		for (int32_t col = seq_col + 1; col < cols; col++) {
-			if (p >= fend || *p == '\n' || *p == '\r')
-				return fail("DSV row #%d has too few columns", row);
-			dsv_field(&p, fend, delim, &flen);
-		}
-		if (p < fend && *p != '\n' && *p != '\r')
+		if (col <= seq_col)
+			return fail("DSV row #%d has no sequence column", row);
+		if (col < cols)
+			return fail("DSV row #%d has too few columns", row);
+		if (t.stop == DSV_AT_DELIM)
 			return fail("DSV row #%d has too many columns", row);
 	}
 	return 0;
@@ -403,14 +415,44 @@ static size_t matrix_bytes(size_t num, bool triangular)
 	return sizeof(int32_t) * (triangular ? num * (num - 1) / 2 : num * num);
 }
 
-int32_t *sa_host_matrix_alloc(size_t num, bool triangular)
+/* Anonymous zero-filled mapping, or -- when the caller found the matrix too large for RAM (output.c:36) -- a
+ * mapping of an unnamed temporary file that disappears with the process (os.c:112-125: O_TMPFILE under /tmp;
+ * $TMPDIR is honoured here, and a file system without O_TMPFILE gets an unlinked mkstemp file instead). */
+int32_t *sa_host_matrix_alloc(size_t num, bool triangular, bool file_backed)
 {
-	const size_t bytes = matrix_bytes(num, triangular);
-	void *p = mmap(NULL, bytes ? bytes : 1, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+	const size_t bytes = matrix_bytes(num, triangular) ? matrix_bytes(num, triangular) : 1;
+	int fd = -1;
+	if (file_backed) {
+		const char *dir = getenv("TMPDIR");
+		if (!dir || !*dir)
+			dir = "/tmp";
+		fd = open(dir, O_TMPFILE | O_RDWR, S_IRUSR | S_IWUSR);
+		if (fd < 0) {
+			char path[4096];
+			snprintf(path, sizeof(path), "%s/seqalign_matrix_XXXXXX", dir);
+			fd = mkstemp(path);
+			if (fd >= 0)
+				unlink(path);
+		}
+		if (fd < 0) {
+			fail("Could not create a temporary file in %s", dir);
+			return NULL;
+		}
+		if (ftruncate(fd, (off_t)bytes) != 0) {
+			fail("Could not create %zu byte temporary file", bytes);
+			close(fd);
+			return NULL;
+		}
+	}
+	void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, fd >= 0 ? MAP_SHARED : MAP_PRIVATE | MAP_ANONYMOUS, fd, 0);
+	if (fd >= 0)
+		close(fd);
 	if (p == MAP_FAILED) {
 		fail("Failed to allocate %.2f GiB for the similarity matrix", (double)bytes / (double)(1 << 30));
 		return NULL;
 	}
+	madvise(p, bytes, MADV_HUGEPAGE);
+	madvise(p, bytes, MADV_DONTDUMP);
 	return p;
 }
 
@@ -420,8 +462,13 @@ void sa_host_matrix_free(int32_t *m, size_t num, bool triangular)
 		munmap(m, matrix_bytes(num, triangular) ? matrix_bytes(num, triangular) : 1);
 }
 
+/* MemAvailable (os.c:262-295).  SA_HOST_MEM_AVAILABLE=<bytes> overrides the probe: the test hook of the
+ * temporary-file branch. */
 size_t sa_host_available_memory(void)
 {
+	const char *forced = getenv("SA_HOST_MEM_AVAILABLE");
+	if (forced && *forced)
+		return (size_t)strtoull(forced, NULL, 10);
 	FILE *f = fopen("/proc/meminfo", "r");
 	if (!f)
 		return 0;
@@ -432,6 +479,14 @@ size_t sa_host_available_memory(void)
 			break;
 	fclose(f);
 	return kb * 1024;
+}
+
+/* output.c:36: a full matrix larger than 3/4 of the available memory goes to temporary file storage (and is then
+ * stored triangular) */
+bool sa_host_matrix_needs_file(size_t num)
+{
+	const size_t avail = sa_host_available_memory();
+	return avail && matrix_bytes(num, false) > avail / 4 * 3;
 }
 
 /* ---- HDF5 writer (reference src/io/format/hdf5.c:14-202) ---------------------------------- */

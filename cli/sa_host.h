@@ -50,10 +50,13 @@ int32_t sa_host_filter(struct sa_host_store *s, float threshold, int threads);
  * number kept (<0 when fewer than 2 remain). */
 int32_t sa_host_compact(struct sa_host_store *s, const uint8_t *keep);
 
-/* Result matrix: anonymous zero-filled mmap (os.c:32-141); bytes = 4*N*N or 4*N(N-1)/2. */
-int32_t *sa_host_matrix_alloc(size_t num, bool triangular);
+/* Result matrix (output.c:16-66, os.c:32-141): zero-filled mapping of 4*N*N or 4*N(N-1)/2 bytes -- anonymous, or of an
+ * unnamed temporary file when `file_backed` (what the reference does once the full matrix exceeds 3/4 of
+ * MemAvailable, sa_host_matrix_needs_file; it then also stores the matrix triangular). */
+int32_t *sa_host_matrix_alloc(size_t num, bool triangular, bool file_backed);
 void sa_host_matrix_free(int32_t *m, size_t num, bool triangular);
-size_t sa_host_available_memory(void); /* MemAvailable, os.c:262-295 */
+size_t sa_host_available_memory(void); /* MemAvailable, os.c:262-295; SA_HOST_MEM_AVAILABLE=<bytes> overrides (tests) */
+bool sa_host_matrix_needs_file(size_t num);
 
 /* HDF5: /sequences (N vlen C strings) + /similarity_matrix (N x N I32LE, symmetric, zero diagonal);
  * chunked only when N > 256, chunk = clamp(largest 64*2^k <= N, 256, 4096), deflate level z on the

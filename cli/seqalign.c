@@ -13,6 +13,7 @@
  */
 #define _GNU_SOURCE
 #include <errno.h>
+#include <omp.h>
 #include <stdarg.h>
 #include <stdbool.h>
 #include <stdio.h>
@@ -323,6 +324,11 @@ int main(int argc, char **argv)
 		return 1;
 	}
 
+	/* -T: host threads (validate_threads, src/system/os.c:466-473).  The alignment itself runs on the device; the
+	 * host's parallel loops are the triangular->full expansion of the HDF5 writer and the CPU filter */
+	if (o.threads > 0)
+		omp_set_num_threads(o.threads);
+
 	info("SEQUENCE ALIGNER (MI355X / HIP)");
 	info("Input: %s", o.input);
 	if (o.output)
@@ -364,22 +370,31 @@ int main(int argc, char **argv)
 	info("Loaded %d sequences", store.in.num);
 	info("Average sequence length: %.2f", (double)store.blob_bytes / (double)store.in.num - 1.0);
 
-	/* output_load: full matrix unless it exceeds 3/4 of available RAM or the device cannot hold it
-	 * (src/io/output.c:35-40) */
+	/* output_load (src/io/output.c:35-55): a full matrix that exceeds 3/4 of the available RAM goes to temporary
+	 * file storage and is stored triangular; so is one the device(s) cannot hold */
 	const size_t n = (size_t)store.in.num;
 	struct sa_output out = { NULL, NULL, n, false };
+	bool pinned = false;
 	if (!o.no_write) {
 		const size_t full_bytes = sizeof(int32_t) * n * n;
-		const size_t avail = sa_host_available_memory();
-		out.triangular = (avail && full_bytes > avail / 4 * 3) || !sa_hip_memory(full_bytes);
+		const bool tmpf = sa_host_matrix_needs_file(n);
+		out.triangular = tmpf || !sa_hip_memory(full_bytes);
 		info("Similarity Matrix dimensions: %zu x %zu%s", n, n, out.triangular ? " (stored triangular)" : "");
+		if (tmpf)
+			info("Similarity Matrix size exceeds memory limits, creating temporary file storage");
 		t0 = now();
-		out.matrix = sa_host_matrix_alloc(n, out.triangular);
-		t_out += now() - t0;
+		out.matrix = sa_host_matrix_alloc(n, out.triangular, tmpf);
 		if (!out.matrix) {
 			err("%s", sa_host_error());
 			return 1;
 		}
+		/* page-lock it for the device->host copies while it is being set up (a file-backed matrix is larger than
+		 * RAM by definition and stays pageable: the library stages those copies) */
+		if (!tmpf) {
+			const size_t bytes = sizeof(int32_t) * (out.triangular ? n * (n - 1) / 2 : n * n);
+			pinned = bytes && sa_hip_host_register(out.matrix, bytes) == 0;
+		}
+		t_out += now() - t0;
 	}
 
 	const long long pairs = (long long)n * ((long long)n - 1) / 2;
@@ -412,6 +427,8 @@ int main(int argc, char **argv)
 		printf("  (device set-up and upload, outside the phases as in the reference: %.3f sec)\n", t_setup);
 		printf("Alignments per second: %.2f\n", t_align > 0 ? (double)pairs / t_align : 0.0);
 	}
+	if (pinned)
+		sa_hip_host_unregister(out.matrix);
 	sa_host_matrix_free(out.matrix, n, out.triangular);
 	sa_host_store_free(&store);
 	return 0;

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 1
+#define SA_ABI_VERSION 2
 
 /* ---- data types shared with the reference ------------------------------- */
 
@@ -86,7 +86,8 @@ struct sa_scoring {
 /* ---- the two reference entry points ------------------------------------- */
 
 /* Replaces `bool cuda_memory(size_t bytes)` (src/interface/seqalign_cuda.h:7,
- * src/interface/seqalign_cuda.c:71-93): true iff the device has bytes*4/3 free.
+ * src/interface/seqalign_cuda.c:71-93): true iff the device has bytes*4/3 free --
+ * on EVERY device sa_hip_align will use (all visible ones, or the first SA_HIP_DEVICES).
  * Caller: output_load (src/io/output.c:37) to choose full vs triangular. */
 bool sa_hip_memory(size_t bytes);
 
@@ -126,6 +127,24 @@ int64_t sa_ctx_pairs(const sa_ctx *ctx);
  * src/bio/align.h:48, src/bio/kernels.cu:32-40,73).  Asynchronous on `stream`
  * (a hipStream_t, NULL = default stream). 0 on success. */
 int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream);
+
+/* The launch/copy loop of cuda_align (src/interface/seqalign_cuda.c:182-292) on a ready context: scores of the
+ * packed range [start, start+count) delivered into the HOST matrix `out` (the WHOLE matrix: packed element p
+ * at out.matrix[p], or full dim x dim; out.matrix == NULL computes and copies nothing, the reference's -W).
+ * Packed destination: double-buffered batches, each batch's device->host copy overlapping the next batch's
+ * kernels.  Full destination with a column-aligned range and N^2 ints of free HBM: the L-shaped shell of every
+ * column batch is expanded on the device and copied while the next batch computes; otherwise batches are
+ * scattered by the host like output_fill (src/io/output.c:76-81).  Device buffers, streams and the page-locking
+ * of a destination that is not yet page-locked are set up BEFORE the timed phase (the reference's allocations and
+ * uploads are outside bench_align_start..end as well); *phase_seconds receives the duration of the loop itself.
+ * sa_hip_align = sa_ctx_create + sa_ctx_align_host per device + sa_ctx_destroy.  0 on success. */
+int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, struct sa_output out, double *phase_seconds);
+
+/* Page-locks / releases a host range for device->host DMA (hipHostRegister).  A host that allocates its result
+ * matrix once (output_load, src/io/output.c:55) registers it there; sa_ctx_align_host / sa_hip_align detect a
+ * registered destination and skip their own temporary registration.  0 on success. */
+int sa_hip_host_register(void *p, size_t bytes);
+int sa_hip_host_unregister(void *p);
 
 /* Exchange format for the multi-GPU all-gather (no reference counterpart: SURVEY 8e): the same scores as
  * int16 when they provably fit -- every |score| <= max_len * max|S| + 2 * max_len * max|gap| <= 32767 for this

@@ -20,6 +20,7 @@ Python/CPU fallback: a missing library or device raises.
 from .binding import (  # noqa: F401
     AlignError,
     Context,
+    PinnedMatrix,
     Scoring,
     SequenceStore,
     device_count,
@@ -36,6 +37,6 @@ from .binding import (  # noqa: F401
 )
 
 __all__ = [
-    "AlignError", "Context", "Scoring", "SequenceStore", "device_count", "device_name", "last_align_seconds", "hip_align", "hip_filter",
+    "AlignError", "Context", "PinnedMatrix", "Scoring", "SequenceStore", "device_count", "device_name", "last_align_seconds", "hip_align", "hip_filter",
     "hip_memory", "library_path", "load_library", "matrix_names", "method_names", "pair_count",
 ]

@@ -50,7 +50,7 @@ ABI_SYMBOLS = (
     "sa_matrix_load", "sa_matrix_count", "sa_matrix_name", "sa_matrix_is_nucleotide", "sa_method_parse",
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
-    "sa_hip_last_align_seconds",
+    "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
 )
 
 
@@ -138,6 +138,12 @@ def load_library() -> C.CDLL:
     lib.sa_last_error.restype = C.c_char_p
     lib.sa_abi_version.restype = C.c_int
     lib.sa_hip_last_align_seconds.restype = C.c_double
+    lib.sa_ctx_align_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _Output, C.POINTER(C.c_double)]
+    lib.sa_ctx_align_host.restype = C.c_int
+    lib.sa_hip_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    lib.sa_hip_host_register.restype = C.c_int
+    lib.sa_hip_host_unregister.argtypes = [C.c_void_p]
+    lib.sa_hip_host_unregister.restype = C.c_int
     _lib = lib
     return lib
 
@@ -320,6 +326,26 @@ def hip_align(store: SequenceStore, scoring: Scoring, triangular: bool = False, 
     return matrix if triangular else matrix.reshape(n, n)
 
 
+class PinnedMatrix:
+    """A host result matrix page-locked once (what a C host does in output_load with sa_hip_host_register), so that
+    repeated deliveries into it are pure DMA.  `.array` is the flat int32 numpy view."""
+
+    def __init__(self, elements: int):
+        self._lib = load_library()
+        self.array = np.zeros(max(int(elements), 1), dtype=np.int32)[:int(elements)]
+        self._registered = False
+        if elements and self._lib.sa_hip_host_register(C.c_void_p(self.array.ctypes.data), self.array.nbytes):
+            raise AlignError(_err())
+        self._registered = bool(elements)
+
+    def close(self) -> None:
+        if self._registered:
+            self._lib.sa_hip_host_unregister(C.c_void_p(self.array.ctypes.data))
+            self._registered = False
+
+    __del__ = close
+
+
 def hip_filter(store: SequenceStore, threshold: float) -> np.ndarray:
     """`filter()` replacement (reference src/bio/filter.c:14-89): boolean keep mask with the sequential semantics
     of `-f threshold`; the similarity relation is computed on the device."""
@@ -385,6 +411,17 @@ class Context:
         """int16 exchange format -> the reference's s32, on the device"""
         if self._lib.sa_hip_widen16(C.c_void_p(d_src16_ptr), C.c_void_p(d_dst32_ptr), count, C.c_void_p(stream)):
             raise AlignError(_err())
+
+    def align_host(self, matrix: Optional[np.ndarray], triangular: bool, start: int = 0, count: Optional[int] = None) -> float:
+        """The reference's launch/copy loop (seqalign_cuda.c:182-292) on this context: scores of the packed range into
+        the host matrix (a flat int32 array: packed N(N-1)/2 or full N*N; None = the reference's -W).  Returns the
+        seconds the loop took (uploads, allocations and page-locking are outside it, as in the reference)."""
+        count = self.pairs - start if count is None else count
+        out = _Output(matrix.ctypes.data if matrix is not None else None, None, self.num, bool(triangular))
+        phase = C.c_double()
+        if self._lib.sa_ctx_align_host(self._h, start, count, out, C.byref(phase)):
+            raise AlignError(_err())
+        return float(phase.value)
 
     def expand_full(self, d_packed_ptr: int, d_full_ptr: int, stream: int = 0) -> None:
         if self._lib.sa_ctx_expand_full(self._h, C.c_void_p(d_packed_ptr), C.c_void_p(d_full_ptr), C.c_void_p(stream)):

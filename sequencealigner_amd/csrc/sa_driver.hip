@@ -80,7 +80,25 @@ struct sa_ctx {
 		int64_t pairs, cells;
 	};
 	std::vector<Timed> events;
+	/* development switches, read once when the context is created */
+	bool env_serial_classes = false, env_stamps = false, env_no_pin = false, env_no_shells = false;
+	int env_chunk = 0;
+	/* host delivery (sa_ctx_align_host): streams, events and buffers, created on first use and kept */
+	struct Deliver {
+		hipStream_t compute = nullptr, copy = nullptr;
+		hipEvent_t done[2] = {}, copied[2] = {};
+		int32_t *d_buf[2] = {};   /* double-buffered batches of packed scores                  */
+		int64_t buf_elems[2] = {};
+		int32_t *h_stage[2] = {}; /* pinned staging for the host-scattered full layout          */
+		int64_t stage_elems[2] = {};
+		int32_t *d_packed = nullptr, *d_full = nullptr; /* full layout, shell schedule          */
+		int64_t packed_elems = 0, full_elems = 0;
+	} dl;
 };
+
+namespace {
+void deliver_release(sa_ctx *ctx);
+}
 
 static void plan_free(sa_ctx::Plan &pl)
 {
@@ -132,22 +150,6 @@ extern "C" const char *sa_hip_device_name(int device)
 		return nullptr;
 	snprintf(name, sizeof(name), "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
 	return name;
-}
-
-/* reference src/interface/seqalign_cuda.c:71-93 */
-extern "C" bool sa_hip_memory(size_t bytes)
-{
-	if (!device_ready(0))
-		return false;
-	size_t free_b = 0, total_b = 0;
-	SA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b), return false);
-	const long double need = (long double)bytes * 4.0L / 3.0L;
-	if ((long double)free_b < need) {
-		sa_set_error("%.2f GiB exceeds available GPU memory (%.2f GiB free)",
-			     (double)(need / (1 << 30)), (double)free_b / (double)(1 << 30));
-		return false;
-	}
-	return true;
 }
 
 /* ---- context ------------------------------------------------------------- */
@@ -313,6 +315,12 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	for (int32_t k = 0; k < in.num; k++)
 		ctx->meta[(size_t)k] = sa_meta{ off[(size_t)k], in.meta[k].len };
 	ctx->off = off;
+	ctx->env_serial_classes = getenv("SA_HIP_SERIAL_CLASSES") != nullptr;
+	ctx->env_stamps = getenv("SA_HIP_STAMPS") != nullptr;
+	ctx->env_no_pin = getenv("SA_HIP_NO_PIN") != nullptr;
+	ctx->env_no_shells = getenv("SA_HIP_NO_SHELLS") != nullptr;
+	if (const char *e = getenv("SA_HIP_CHUNK")) /* development switch: fixed stream length */
+		ctx->env_chunk = std::max(1, std::min(SA_SYS_CHUNK, atoi(e)));
 	systolic_setup(ctx);
 	int8_t sub8[SA_SUB_DIM * SA_SUB_DIM];
 	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++)
@@ -353,6 +361,8 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		}
 		if (!streams_ok)
 			break;
+		/* code objects are loaded lazily at the first launch: do it here, with the other set-up */
+		SA_HIP_CHECK(sa_warm_kernels(sc->method), break);
 		ok = true;
 	} while (0);
 	if (!ok) {
@@ -372,6 +382,7 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 		(void)hipEventDestroy(ev.e1);
 	}
 	plan_release(ctx);
+	deliver_release(ctx);
 	(void)hipFree(ctx->d_codes);
 	(void)hipFree(ctx->d_meta);
 	(void)hipFree(ctx->d_off);
@@ -572,8 +583,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		int32_t chunk = SA_SYS_CHUNK;
 		while (chunk > 8 && count / (4 * chunk) < want_tiles)
 			chunk >>= 1;
-		if (const char *e = getenv("SA_HIP_CHUNK")) /* development switch: fixed stream length */
-			chunk = std::max(1, std::min(SA_SYS_CHUNK, atoi(e)));
+		if (ctx->env_chunk)
+			chunk = ctx->env_chunk;
 		plan.chunk = chunk;
 	}
 	const int32_t j0 = column_of(start), j1 = column_of(end - 1);
@@ -721,7 +732,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 
 	/* systolic streaming kernels: one persistent launch per column-length class; with several classes the
 	 * launches go to side streams forked from / joined back into the caller's stream so they run concurrently */
-	const bool fan_out = ctx->plan->classes.size() > 1 && !getenv("SA_HIP_SERIAL_CLASSES");
+	const bool fan_out = ctx->plan->classes.size() > 1 && !ctx->env_serial_classes;
 	const size_t slot = (size_t)(ctx->call_no++ % sa_ctx::COUNTER_SLOTS);
 	unsigned *const counters = ctx->d_counters + slot * sa_ctx::COUNTERS_PER_SLOT;
 	if (ctx->slot_done[slot]) { /* 256 calls ago, possibly on another stream: normally long complete */
@@ -788,7 +799,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
 		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
 		unsigned long long *d_stamps = nullptr;
-		if (getenv("SA_HIP_STAMPS")) {
+		if (ctx->env_stamps) {
 			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
 			a.stamps = d_stamps;
 		}
@@ -954,11 +965,14 @@ extern "C" int32_t sa_hip_filter(struct sa_input in, float threshold, uint8_t *k
 	return kept;
 }
 
-/* ---- sa_hip_align: the cuda_align replacement (host buffers in, host matrix out) ---------- */
+/* ---- host delivery: the launch/copy loop of cuda_align (src/interface/seqalign_cuda.c:182-292) ---- */
 
 namespace {
 
 constexpr int64_t BATCH_PAIRS = (int64_t)64 << 20; /* reference batch: src/interface/seqalign_cuda.c:136 */
+constexpr int64_t FINAL_BATCH_PAIRS = (int64_t)3 << 20; /* the batch whose device->host copy nothing overlaps */
+
+int64_t tri_of(int64_t j) { return j * (j - 1) / 2; }
 
 /* scatter a packed slice into the full symmetric host matrix (what output_fill does per column,
  * reference src/io/output.c:76-81) */
@@ -977,166 +991,346 @@ void host_scatter_full(int32_t *matrix, size_t dim, const int32_t *slice, int64_
 	}
 }
 
-/* one device: computes packed range [lo,hi) and delivers it to the host matrix */
-bool run_device_range(int device, const sa_input &in, const sa_output &out, const sa_scoring &sc, int64_t lo,
-		      int64_t hi, bool whole_job, std::string &err, double &phase_seconds)
+/* is [p, p+bytes) already page-locked and known to the HIP runtime (hipHostMalloc / hipHostRegister)? */
+bool host_range_is_pinned(const void *p)
 {
-	sa_ctx *ctx = sa_ctx_create(device, in, &sc);
-	if (!ctx) {
-		err = sa_last_error();
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+		(void)hipGetLastError();
 		return false;
 	}
-	bool ok = false;
-	int32_t *d_buf[2] = { nullptr, nullptr };
-	int32_t *d_full = nullptr;
-	int32_t *h_stage[2] = { nullptr, nullptr };
-	int32_t *pinned_dst = nullptr;
-	hipStream_t compute = nullptr, copy = nullptr;
-	hipEvent_t done[2] = { nullptr, nullptr }, copied[2] = { nullptr, nullptr };
-	const int64_t total = hi - lo;
-	const size_t dim = (size_t)in.num;
-	do {
-		SA_HIP_CHECK(hipStreamCreate(&compute), break);
-		SA_HIP_CHECK(hipStreamCreate(&copy), break);
-		for (int k = 0; k < 2; k++) {
-			SA_HIP_CHECK(hipEventCreateWithFlags(&done[k], hipEventDisableTiming), goto out);
-			SA_HIP_CHECK(hipEventCreateWithFlags(&copied[k], hipEventDisableTiming), goto out);
-		}
-		/* fast path for the full layout: whole job on this device and N^2 + packed fit in HBM */
-		if (!out.triangular && whole_job && out.matrix) {
-			size_t free_b = 0, total_b = 0;
-			SA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b), break);
-			const size_t need = sizeof(int32_t) * (dim * dim + (size_t)total);
-			if ((long double)need * 4 / 3 < (long double)free_b) {
-				SA_HIP_CHECK(hipMalloc(&d_buf[0], sizeof(int32_t) * (size_t)total), break);
-				SA_HIP_CHECK(hipMalloc(&d_full, sizeof(int32_t) * dim * dim), break);
-				const auto t_phase = std::chrono::steady_clock::now();
-				if (sa_ctx_align_range(ctx, lo, total, d_buf[0], compute))
-					break;
-				if (sa_ctx_expand_full(ctx, d_buf[0], d_full, compute))
-					break;
-				if (!getenv("SA_HIP_NO_PIN")) { /* page-lock the destination while the kernels run */
-					if (hipHostRegister(out.matrix, sizeof(int32_t) * dim * dim, hipHostRegisterDefault) == hipSuccess)
-						pinned_dst = out.matrix;
-					else
-						(void)hipGetLastError();
-				}
-				SA_HIP_CHECK(hipMemcpyAsync(out.matrix, d_full, sizeof(int32_t) * dim * dim,
-							    hipMemcpyDeviceToHost, compute), break);
-				SA_HIP_CHECK(hipStreamSynchronize(compute), break);
-				phase_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
-				ok = true;
+	return attr.type == hipMemoryTypeHost;
+}
+
+/* MemAvailable of the host: a destination larger than half of it (a file-backed matrix, src/io/output.c:36) is not
+ * page-locked, its copies are staged by the runtime instead */
+size_t host_available_bytes()
+{
+	size_t kb = 0;
+	if (FILE *f = fopen("/proc/meminfo", "r")) {
+		char line[256];
+		while (fgets(line, sizeof(line), f))
+			if (sscanf(line, "MemAvailable: %zu kB", &kb) == 1)
 				break;
-			}
-		}
-		/* general path: double-buffered batches of packed scores; a job that would fit one reference-size
-		 * batch is still cut in ~8 pieces so the device->host copy of a piece overlaps the next kernels */
-		int64_t batch = std::min<int64_t>(std::max<int64_t>(total, 1), BATCH_PAIRS);
-		if (out.matrix && total > ((int64_t)8 << 20))
-			batch = std::min<int64_t>(batch, std::max<int64_t>((total + 7) / 8, (int64_t)4 << 20));
-		for (int k = 0; k < 2; k++) {
-			SA_HIP_CHECK(hipMalloc(&d_buf[k], sizeof(int32_t) * (size_t)batch), goto out);
-		}
-		if (out.matrix && !out.triangular) {
-			for (int k = 0; k < 2; k++) {
-				SA_HIP_CHECK(hipHostMalloc(&h_stage[k], sizeof(int32_t) * (size_t)batch), goto out);
-			}
-		}
-		/* triangular destination: page-lock the caller's slice for the duration of the call so the copies
-		 * are true DMA and overlap the kernels (a pageable destination is staged and serialises).  Best
-		 * effort: if registration fails the copies still work, only slower. */
-		if (out.matrix && out.triangular && total > 0 && !getenv("SA_HIP_NO_PIN")) {
-			if (hipHostRegister(out.matrix + lo, sizeof(int32_t) * (size_t)total, hipHostRegisterDefault) == hipSuccess)
-				pinned_dst = out.matrix + lo;
-			else
-				(void)hipGetLastError();
-		}
-		{
-			const auto t_phase = std::chrono::steady_clock::now();
-			int64_t issued = 0, delivered = 0;
-			int nb = 0;
-			struct Pending {
-				int64_t start, count;
-				int buf;
-			} pend[2];
-			int npend = 0;
-			bool failed = false;
-			auto deliver_oldest = [&]() -> bool {
-				Pending pd = pend[0];
-				SA_HIP_CHECK(hipEventSynchronize(copied[pd.buf]), return false);
-				if (out.matrix && !out.triangular)
-					host_scatter_full(out.matrix, dim, h_stage[pd.buf], pd.start, pd.count);
-				delivered += pd.count;
-				pend[0] = pend[1];
-				npend--;
-				return true;
-			};
-			while (issued < total && !failed) {
-				const int b = nb & 1;
-				if (npend == 2 && !deliver_oldest()) {
-					failed = true;
-					break;
-				}
-				const int64_t cnt = std::min(batch, total - issued);
-				if (sa_ctx_align_range(ctx, lo + issued, cnt, d_buf[b], compute)) {
-					failed = true;
-					break;
-				}
-				SA_HIP_CHECK(hipEventRecord(done[b], compute), failed = true; break);
-				SA_HIP_CHECK(hipStreamWaitEvent(copy, done[b], 0), failed = true; break);
-				if (out.matrix) {
-					int32_t *dst = out.triangular ? out.matrix + lo + issued : h_stage[b];
-					SA_HIP_CHECK(hipMemcpyAsync(dst, d_buf[b], sizeof(int32_t) * (size_t)cnt,
-								    hipMemcpyDeviceToHost, copy), failed = true; break);
-				}
-				SA_HIP_CHECK(hipEventRecord(copied[b], copy), failed = true; break);
-				/* the next kernel that reuses this buffer must wait for its copy-out */
-				SA_HIP_CHECK(hipStreamWaitEvent(compute, copied[b], 0), failed = true; break);
-				pend[npend++] = Pending{ lo + issued, cnt, b };
-				issued += cnt;
-				nb++;
-			}
-			while (!failed && npend)
-				if (!deliver_oldest())
-					failed = true;
-			if (failed)
-				break;
-			SA_HIP_CHECK(hipStreamSynchronize(compute), break);
-			SA_HIP_CHECK(hipStreamSynchronize(copy), break);
-			phase_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
-			(void)delivered;
-		}
-		ok = true;
-	} while (0);
-out:
-	if (!ok)
-		err = sa_last_error();
-	for (int k = 0; k < 2; k++) {
-		if (d_buf[k])
-			(void)hipFree(d_buf[k]);
-		if (h_stage[k])
-			(void)hipHostFree(h_stage[k]);
-		if (done[k])
-			(void)hipEventDestroy(done[k]);
-		if (copied[k])
-			(void)hipEventDestroy(copied[k]);
+		fclose(f);
 	}
-	if (pinned_dst)
-		(void)hipHostUnregister(pinned_dst);
-	if (d_full)
-		(void)hipFree(d_full);
-	if (compute)
-		(void)hipStreamDestroy(compute);
-	if (copy)
-		(void)hipStreamDestroy(copy);
-	sa_ctx_destroy(ctx);
-	return ok;
+	return kb * 1024;
+}
+
+bool deliver_resources(sa_ctx *ctx)
+{
+	auto &d = ctx->dl;
+	if (d.compute)
+		return true;
+	SA_HIP_CHECK(hipStreamCreateWithFlags(&d.compute, hipStreamNonBlocking), return false);
+	SA_HIP_CHECK(hipStreamCreateWithFlags(&d.copy, hipStreamNonBlocking), return false);
+	for (int k = 0; k < 2; k++) {
+		SA_HIP_CHECK(hipEventCreateWithFlags(&d.done[k], hipEventDisableTiming), return false);
+		SA_HIP_CHECK(hipEventCreateWithFlags(&d.copied[k], hipEventDisableTiming), return false);
+	}
+	return true;
+}
+
+template <typename T> bool grow(T *&ptr, int64_t &have, int64_t want, bool host)
+{
+	if (have >= want)
+		return true;
+	if (ptr) {
+		if (host)
+			(void)hipHostFree(ptr);
+		else
+			(void)hipFree(ptr);
+		ptr = nullptr;
+		have = 0;
+	}
+	if (host) {
+		SA_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&ptr), sizeof(T) * (size_t)want), return false);
+	} else {
+		SA_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&ptr), sizeof(T) * (size_t)want), return false);
+	}
+	have = want;
+	return true;
+}
+
+void deliver_release(sa_ctx *ctx)
+{
+	auto &d = ctx->dl;
+	for (int k = 0; k < 2; k++) {
+		if (d.d_buf[k])
+			(void)hipFree(d.d_buf[k]);
+		if (d.h_stage[k])
+			(void)hipHostFree(d.h_stage[k]);
+		if (d.done[k])
+			(void)hipEventDestroy(d.done[k]);
+		if (d.copied[k])
+			(void)hipEventDestroy(d.copied[k]);
+	}
+	if (d.d_packed)
+		(void)hipFree(d.d_packed);
+	if (d.d_full)
+		(void)hipFree(d.d_full);
+	if (d.compute)
+		(void)hipStreamDestroy(d.compute);
+	if (d.copy)
+		(void)hipStreamDestroy(d.copy);
+	d = sa_ctx::Deliver();
+}
+
+/* Full layout, column-aligned range [tri(j0), tri(j1)), everything resident: the packed scores of the range stay
+ * on the device, every batch of columns [ja, jb) is expanded into its L-shaped shell of the full matrix --
+ * rows [ja, jb) x cols [0, jb) and rows [0, ja) x cols [ja, jb), all of whose pairs belong to the batch -- and
+ * the two rectangles go to the host as strided copies while the next batch computes.  The shells of all batches
+ * tile the matrix exactly once, so the device->host traffic is N^2 elements and nearly all of it is overlapped. */
+bool deliver_full_shells(sa_ctx *ctx, int64_t j0, int64_t j1, int32_t *matrix, double &phase_seconds)
+{
+	auto &d = ctx->dl;
+	const int64_t start = tri_of(j0);
+	const size_t dim = (size_t)ctx->num;
+	/* batches cut at column starts.  The copies run ~8x faster than the kernels produce data, so only the LAST
+	 * batch's copy is exposed: the batches shrink geometrically (half of what is left, at most one reference batch)
+	 * down to a small final one, which keeps the launches few and long (short launches run at a lower rate) */
+	std::vector<int64_t> cuts{ j0 };
+	for (int64_t j = j0; j < j1;) {
+		const int64_t left = tri_of(j1) - tri_of(j);
+		const int64_t want = left <= FINAL_BATCH_PAIRS ? left : std::min<int64_t>(BATCH_PAIRS, left / 2);
+		int64_t jn = column_of(std::min(tri_of(j) + want, tri_of(j1) - 1)) + 1;
+		jn = std::min(std::max(jn, j + 1), j1);
+		cuts.push_back(jn);
+		j = jn;
+	}
+	const auto t_phase = std::chrono::steady_clock::now();
+	for (size_t b = 0; b + 1 < cuts.size(); b++) {
+		const int64_t ja = cuts[b], jb = cuts[b + 1];
+		const int64_t lo = tri_of(ja), cnt = tri_of(jb) - lo;
+		if (cnt > 0 && sa_ctx_align_range(ctx, lo, cnt, d.d_packed + (lo - start), d.compute))
+			return false;
+		SA_HIP_CHECK(sa_launch_expand_shell(d.d_packed, start, d.d_full, ctx->num, (int32_t)ja, (int32_t)jb, d.compute),
+			     return false);
+		SA_HIP_CHECK(hipEventRecord(d.done[0], d.compute), return false);
+		SA_HIP_CHECK(hipStreamWaitEvent(d.copy, d.done[0], 0), return false);
+		/* rows [ja, jb) x cols [0, jb) */
+		SA_HIP_CHECK(hipMemcpy2DAsync(matrix + (size_t)ja * dim, dim * sizeof(int32_t), d.d_full + (size_t)ja * dim,
+					      dim * sizeof(int32_t), (size_t)jb * sizeof(int32_t), (size_t)(jb - ja),
+					      hipMemcpyDeviceToHost, d.copy), return false);
+		if (ja > 0) { /* rows [0, ja) x cols [ja, jb) */
+			SA_HIP_CHECK(hipMemcpy2DAsync(matrix + (size_t)ja, dim * sizeof(int32_t), d.d_full + (size_t)ja,
+						      dim * sizeof(int32_t), (size_t)(jb - ja) * sizeof(int32_t), (size_t)ja,
+						      hipMemcpyDeviceToHost, d.copy), return false);
+		}
+	}
+	SA_HIP_CHECK(hipStreamSynchronize(d.compute), return false);
+	SA_HIP_CHECK(hipStreamSynchronize(d.copy), return false);
+	phase_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
+	return true;
+}
+
+/* General path: double-buffered batches of packed scores; a job that would fit one reference-size batch is still
+ * cut in ~10 pieces so that the device->host copy of a piece overlaps the kernels of the next.  Packed
+ * destination: straight into the caller's matrix; full destination (range not column-aligned, or the device
+ * cannot hold N^2): staged in pinned memory and scattered by the host like output_fill. */
+bool deliver_batches(sa_ctx *ctx, int64_t lo, int64_t total, const sa_output &out, int64_t batch, bool shrink,
+		     double &phase_seconds)
+{
+	auto &d = ctx->dl;
+	const size_t dim = (size_t)ctx->num;
+	const bool stage = out.matrix && !out.triangular;
+	const auto t_phase = std::chrono::steady_clock::now();
+	int64_t issued = 0;
+	int nb = 0;
+	struct Pending {
+		int64_t start, count;
+		int buf;
+	} pend[2];
+	int npend = 0;
+	auto deliver_oldest = [&]() -> bool {
+		const Pending pd = pend[0];
+		SA_HIP_CHECK(hipEventSynchronize(d.copied[pd.buf]), return false);
+		if (stage)
+			host_scatter_full(out.matrix, dim, d.h_stage[pd.buf], pd.start, pd.count);
+		pend[0] = pend[1];
+		npend--;
+		return true;
+	};
+	while (issued < total) {
+		const int b = nb & 1;
+		if (npend == 2 && !deliver_oldest())
+			return false;
+		/* `shrink`: half of what is left (see deliver_full_shells), else fixed-size batches */
+		const int64_t left = total - issued;
+		const int64_t cnt = !shrink || left <= FINAL_BATCH_PAIRS ? std::min(batch, left) : std::min(batch, (left + 1) / 2);
+		if (sa_ctx_align_range(ctx, lo + issued, cnt, d.d_buf[b], d.compute))
+			return false;
+		SA_HIP_CHECK(hipEventRecord(d.done[b], d.compute), return false);
+		SA_HIP_CHECK(hipStreamWaitEvent(d.copy, d.done[b], 0), return false);
+		if (out.matrix) {
+			int32_t *dst = out.triangular ? out.matrix + lo + issued : d.h_stage[b];
+			SA_HIP_CHECK(hipMemcpyAsync(dst, d.d_buf[b], sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, d.copy),
+				     return false);
+		}
+		SA_HIP_CHECK(hipEventRecord(d.copied[b], d.copy), return false);
+		/* the next kernel that reuses this buffer must wait for its copy-out */
+		SA_HIP_CHECK(hipStreamWaitEvent(d.compute, d.copied[b], 0), return false);
+		pend[npend++] = Pending{ lo + issued, cnt, b };
+		issued += cnt;
+		nb++;
+	}
+	while (npend)
+		if (!deliver_oldest())
+			return false;
+	SA_HIP_CHECK(hipStreamSynchronize(d.compute), return false);
+	SA_HIP_CHECK(hipStreamSynchronize(d.copy), return false);
+	phase_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
+	return true;
 }
 
 } // namespace
 
+extern "C" int sa_hip_host_register(void *p, size_t bytes)
+{
+	if (!p || !bytes) {
+		sa_set_error("sa_hip_host_register: null range");
+		return 1;
+	}
+	if (!device_ready(0))
+		return 1;
+	SA_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterPortable), return 1);
+	return 0;
+}
+
+extern "C" int sa_hip_host_unregister(void *p)
+{
+	if (!p)
+		return 0;
+	SA_HIP_CHECK(hipHostUnregister(p), return 1);
+	return 0;
+}
+
+extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, struct sa_output out, double *phase_seconds)
+{
+	if (phase_seconds)
+		*phase_seconds = 0.0;
+	if (!ctx || start < 0 || count < 0 || start + count > ctx->pairs) {
+		sa_set_error("sa_ctx_align_host: bad range [%lld,+%lld) of %lld pairs", (long long)start, (long long)count,
+			     ctx ? (long long)ctx->pairs : -1LL);
+		return 1;
+	}
+	if (out.matrix && out.dim != (size_t)ctx->num) {
+		sa_set_error("sa_ctx_align_host: output dim %zu does not match %d sequences", out.dim, ctx->num);
+		return 1;
+	}
+	if (count == 0)
+		return 0;
+	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
+	if (!deliver_resources(ctx))
+		return 1;
+	auto &d = ctx->dl;
+	const size_t dim = (size_t)ctx->num;
+	const int64_t total = count;
+
+	/* ---- set-up, outside the timed phase like the reference's allocations (seqalign_cuda.c:125-168) ---- */
+	/* full layout: the shell schedule needs a column-aligned range and N^2 + the range's packed scores in HBM */
+	bool shells = false;
+	int64_t j0 = 0, j1 = 0;
+	if (out.matrix && !out.triangular && !ctx->env_no_shells) {
+		j0 = start == 0 ? 0 : column_of(start);
+		j1 = column_of(start + count - 1) + 1;
+		if (tri_of(j0) == start && tri_of(j1) == start + count) {
+			size_t free_b = 0, total_b = 0;
+			SA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b), return 1);
+			const long double have = (long double)free_b + sizeof(int32_t) * ((long double)d.packed_elems + (long double)d.full_elems);
+			const long double need = sizeof(int32_t) * ((long double)dim * dim + (long double)total);
+			shells = need * 4 / 3 < have;
+		}
+	}
+	int64_t batch = 0;
+	if (shells) {
+		if (!grow(d.d_packed, d.packed_elems, total, false) || !grow(d.d_full, d.full_elems, (int64_t)(dim * dim), false))
+			return 1;
+	} else {
+		batch = std::min<int64_t>(std::max<int64_t>(total, 1), BATCH_PAIRS);
+		if (out.matrix && total > FINAL_BATCH_PAIRS)
+			batch = std::min<int64_t>(batch, (total + 1) / 2);
+		for (int k = 0; k < 2; k++)
+			if (!grow(d.d_buf[k], d.buf_elems[k], batch, false))
+				return 1;
+		if (out.matrix && !out.triangular)
+			for (int k = 0; k < 2; k++)
+				if (!grow(d.h_stage[k], d.stage_elems[k], batch, true))
+					return 1;
+	}
+	/* Page-lock the destination so that the copies are true DMA and overlap the kernels (a pageable destination is
+	 * staged through a bounce buffer and serialises).  A caller that allocated the matrix with sa_hip_host_register /
+	 * hipHostMalloc has done this already.  Best effort: if registration fails the copies still work, only slower. */
+	void *pinned_here = nullptr;
+	if (out.matrix && !ctx->env_no_pin && (out.triangular || shells)) {
+		int32_t *base = out.triangular ? out.matrix + start : out.matrix;
+		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)total : dim * dim);
+		const size_t avail = host_available_bytes();
+		if (!host_range_is_pinned(base) && (!avail || bytes <= avail / 2)) {
+			if (hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess)
+				pinned_here = base;
+			else
+				(void)hipGetLastError();
+		}
+	}
+	SA_HIP_CHECK(hipDeviceSynchronize(), return 1);
+
+	/* ---- the launch/copy loop: what the reference brackets with bench_align_start/end ---- */
+	double phase = 0.0;
+	const bool ok = shells ? deliver_full_shells(ctx, j0, j1, out.matrix, phase)
+			       : deliver_batches(ctx, start, total, out, batch, out.matrix != nullptr, phase);
+	if (!ok) { /* leave nothing in flight that still targets the caller's memory */
+		(void)hipStreamSynchronize(d.compute);
+		(void)hipStreamSynchronize(d.copy);
+	}
+	if (pinned_here)
+		(void)hipHostUnregister(pinned_here);
+	if (phase_seconds)
+		*phase_seconds = phase;
+	return ok ? 0 : 1;
+}
+
+/* ---- sa_hip_align: the cuda_align replacement (host buffers in, host matrix out) ---------- */
+
 /* launch/copy phase of the last successful sa_hip_align call (the reference's bench_align_start..end bracket) */
 static std::atomic<double> g_last_align_seconds{ 0.0 };
+
+/* devices sa_hip_align spreads a job over: all visible ones, or the first SA_HIP_DEVICES */
+static int devices_in_use(void)
+{
+	int ndev = sa_hip_device_count();
+	if (const char *env = getenv("SA_HIP_DEVICES")) {
+		const int want = atoi(env);
+		if (want >= 1 && want < ndev)
+			ndev = want;
+	}
+	return ndev;
+}
+
+/* reference src/interface/seqalign_cuda.c:71-93; with several devices the answer must hold on each of them */
+extern "C" bool sa_hip_memory(size_t bytes)
+{
+	const int ndev = devices_in_use();
+	if (ndev <= 0) {
+		sa_set_error("No HIP devices available; libseqalign_hip has no CPU fallback");
+		return false;
+	}
+	const long double need = (long double)bytes * 4.0L / 3.0L;
+	for (int dev = 0; dev < ndev; dev++) {
+		if (!device_ready(dev))
+			return false;
+		size_t free_b = 0, total_b = 0;
+		SA_HIP_CHECK(hipMemGetInfo(&free_b, &total_b), return false);
+		if ((long double)free_b < need) {
+			sa_set_error("%.2f GiB exceeds available GPU memory (%.2f GiB free on device %d)",
+				     (double)(need / (1 << 30)), (double)free_b / (double)(1 << 30), dev);
+			(void)hipSetDevice(0);
+			return false;
+		}
+	}
+	(void)hipSetDevice(0);
+	return true;
+}
 
 extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const struct sa_scoring *sc)
 {
@@ -1148,55 +1342,80 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 		sa_set_error("sa_hip_align: output dim %zu does not match %d sequences", out.dim, in.num);
 		return false;
 	}
-	int ndev = sa_hip_device_count();
+	int ndev = devices_in_use();
 	if (ndev <= 0) {
 		sa_set_error("No HIP devices available; libseqalign_hip has no CPU fallback");
 		return false;
 	}
-	if (const char *env = getenv("SA_HIP_DEVICES")) {
-		const int want = atoi(env);
-		if (want >= 1 && want < ndev)
-			ndev = want;
-	}
 	const int64_t pairs = (int64_t)in.num * (in.num - 1) / 2;
 	/* SA_HIP_SPLIT=n (testing aid): run the multi-device code path with n work-balanced slices even when
 	 * fewer devices are visible -- slice k goes to device k mod visible */
-	int nvisible = ndev, split = 0;
+	const int nvisible = ndev;
+	int split = 0;
 	if (const char *env = getenv("SA_HIP_SPLIT"))
 		split = atoi(env);
 	if (split >= 2 && pairs >= split)
 		ndev = split;
 	else if (pairs < (int64_t)ndev * 4096)
 		ndev = 1;
-	if (ndev == 1) {
-		std::string err;
-		double phase = 0.0;
-		if (!run_device_range(0, in, out, *sc, 0, pairs, true, err, phase)) {
-			sa_set_error("%s", err.c_str());
+	/* One device per slice of the packed index, cut by DP work (sa_pairs_partition); every device delivers its slice
+	 * straight into the host matrix -- the host is the destination, so no device-to-device exchange is needed
+	 * (DESIGN.md 6).  Full layout: the cuts are moved to column starts so that every slice is a set of whole
+	 * columns and can use the shell schedule. */
+	std::vector<int64_t> bounds((size_t)ndev + 1, 0);
+	bounds[(size_t)ndev] = pairs;
+	if (ndev > 1) {
+		if (sa_pairs_partition(in.meta, in.num, ndev, bounds.data()))
 			return false;
-		}
-		g_last_align_seconds.store(phase);
-		return true;
+		if (out.matrix && !out.triangular)
+			for (int k = 1; k < ndev; k++)
+				bounds[(size_t)k] = std::max(bounds[(size_t)k - 1], tri_of(column_of(bounds[(size_t)k])));
 	}
-	/* several devices in one process: range-partition the packed index by DP work, one host
-	 * thread per device, every device delivers its slice straight into the host matrix */
-	std::vector<int64_t> bounds((size_t)ndev + 1);
-	if (sa_pairs_partition(in.meta, in.num, ndev, bounds.data()))
-		return false;
-	std::vector<std::thread> threads;
+	/* several slices share one destination: page-lock it once for all of them (set-up, outside the timed phase) */
+	void *pinned_here = nullptr;
+	if (ndev > 1 && out.matrix && !getenv("SA_HIP_NO_PIN") && device_ready(0) && !host_range_is_pinned(out.matrix)) {
+		const size_t n = (size_t)in.num;
+		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)pairs : n * n);
+		if (hipHostRegister(out.matrix, bytes, hipHostRegisterPortable) == hipSuccess)
+			pinned_here = out.matrix;
+		else
+			(void)hipGetLastError();
+	}
 	std::vector<std::string> errs((size_t)ndev);
 	std::vector<char> oks((size_t)ndev, 0);
 	std::vector<double> phases((size_t)ndev, 0.0);
-	for (int d = 0; d < ndev; d++)
-		threads.emplace_back([&, d]() {
-			oks[(size_t)d] = run_device_range(d % nvisible, in, out, *sc, bounds[(size_t)d],
-							  bounds[(size_t)d + 1], false, errs[(size_t)d], phases[(size_t)d]);
-		});
-	for (auto &t : threads)
-		t.join();
-	for (int d = 0; d < ndev; d++)
-		if (!oks[(size_t)d]) {
-			sa_set_error("device %d: %s", d, errs[(size_t)d].c_str());
+	auto run = [&](int k) {
+		const int64_t lo = bounds[(size_t)k], hi = bounds[(size_t)k + 1];
+		if (hi <= lo) {
+			oks[(size_t)k] = 1;
+			return;
+		}
+		sa_ctx *ctx = sa_ctx_create(k % nvisible, in, sc);
+		if (ctx && sa_ctx_align_host(ctx, lo, hi - lo, out, &phases[(size_t)k]) == 0)
+			oks[(size_t)k] = 1;
+		else
+			errs[(size_t)k] = sa_last_error();
+		sa_ctx_destroy(ctx);
+	};
+	if (ndev == 1) {
+		run(0);
+	} else {
+		std::vector<std::thread> threads;
+		for (int k = 0; k < ndev; k++)
+			threads.emplace_back(run, k);
+		for (auto &t : threads)
+			t.join();
+	}
+	if (pinned_here) {
+		(void)hipSetDevice(0);
+		(void)hipHostUnregister(pinned_here);
+	}
+	for (int k = 0; k < ndev; k++)
+		if (!oks[(size_t)k]) {
+			if (ndev > 1)
+				sa_set_error("device %d: %s", k % nvisible, errs[(size_t)k].c_str());
+			else
+				sa_set_error("%s", errs[(size_t)k].c_str());
 			return false;
 		}
 	g_last_align_seconds.store(*std::max_element(phases.begin(), phases.end()));

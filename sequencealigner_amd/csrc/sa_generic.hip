@@ -184,6 +184,33 @@ __global__ __launch_bounds__(256) void sa_k_expand_full(const int32_t *__restric
 	}
 }
 
+/* The L-shaped shell of the full matrix owned by columns [ja, jb): rows [ja, jb) x cols [0, jb) (region A, row-major
+ * first) and rows [0, ja) x cols [ja, jb) (region B).  Every element's pair has its larger index in [ja, jb), i.e.
+ * belongs to the packed range tri(ja) .. tri(jb) that was just computed; packed[p - pbase] holds pair p. */
+__global__ __launch_bounds__(256) void sa_k_expand_shell(const int32_t *__restrict__ packed, int64_t pbase,
+							   int32_t *__restrict__ full, int32_t num, int32_t ja, int32_t jb)
+{
+	const int64_t na = (int64_t)(jb - ja) * jb, nb = (int64_t)ja * (jb - ja);
+	for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < na + nb;
+	     e += (int64_t)gridDim.x * blockDim.x) {
+		int64_t r, c;
+		if (e < na) {
+			r = ja + e / jb;
+			c = e % jb;
+		} else {
+			const int64_t f = e - na;
+			r = f / (jb - ja);
+			c = ja + f % (jb - ja);
+		}
+		int32_t v = 0;
+		if (r != c) {
+			const int64_t lo = r < c ? r : c, hi = r < c ? c : r;
+			v = packed[hi * (hi - 1) / 2 + lo - pbase];
+		}
+		full[r * num + c] = v;
+	}
+}
+
 } // namespace
 
 hipError_t sa_launch_generic(int method, const SaGenericArgs &a, int blocks, hipStream_t s)
@@ -238,6 +265,19 @@ hipError_t sa_launch_widen16(const int16_t *src, int32_t *dst, int64_t count, hi
 	return hipGetLastError();
 }
 
+hipError_t sa_launch_expand_shell(const int32_t *packed, int64_t pbase, int32_t *full, int32_t num, int32_t ja, int32_t jb,
+				  hipStream_t s)
+{
+	const int64_t total = (int64_t)(jb - ja) * jb + (int64_t)ja * (jb - ja);
+	if (total <= 0)
+		return hipSuccess;
+	int64_t blocks = (total + 255) / 256;
+	if (blocks > 256 * 16)
+		blocks = 256 * 16;
+	hipLaunchKernelGGL(sa_k_expand_shell, dim3((unsigned)blocks), dim3(256), 0, s, packed, pbase, full, num, ja, jb);
+	return hipGetLastError();
+}
+
 hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t num, hipStream_t s)
 {
 	const int64_t total = (int64_t)num * num;
@@ -246,4 +286,11 @@ hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t n
 		blocks = 256 * 16;
 	hipLaunchKernelGGL(sa_k_expand_full, dim3((unsigned)blocks), dim3(256), 0, s, packed, full, num);
 	return hipGetLastError();
+}
+
+/* see sa_warm_kernels: the pair-per-wave, expand and widen kernels live in this translation unit */
+hipError_t sa_warm_generic(void)
+{
+	hipFuncAttributes attr;
+	return hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&sa_k_expand_full));
 }

@@ -100,6 +100,8 @@ struct SaSysArgs {
 
 /* `workgroups` persistent workgroups pull the launch's wave-tiles from a.counter */
 hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workgroups, hipStream_t s);
+/* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */
+hipError_t sa_warm_kernels(int method);
 
 /* ---- launchers implemented in the .hip files ---------------------------- */
 hipError_t sa_launch_generic(int method, const SaGenericArgs &a, int blocks, hipStream_t s);
@@ -111,6 +113,8 @@ hipError_t sa_launch_filter_relation(const uint8_t *codes, const int32_t *off, i
 				      unsigned long long *rel, int32_t jt0, int32_t tile_rows, hipStream_t s);
 
 hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t num, hipStream_t s);
+hipError_t sa_launch_expand_shell(const int32_t *packed, int64_t pbase, int32_t *full, int32_t num, int32_t ja, int32_t jb,
+				  hipStream_t s);
 hipError_t sa_launch_widen16(const int16_t *src, int32_t *dst, int64_t count, hipStream_t s);
 
 #endif /* SA_INTERNAL_H */

@@ -18,3 +18,14 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 		return hipErrorInvalidValue;
 	}
 }
+
+hipError_t sa_warm_systolic_nw(void);
+hipError_t sa_warm_systolic_ga(void);
+hipError_t sa_warm_systolic_sw(void);
+hipError_t sa_warm_generic(void);
+
+hipError_t sa_warm_kernels(int method)
+{
+	hipError_t e = method == SA_METHOD_NW ? sa_warm_systolic_nw() : method == SA_METHOD_GA ? sa_warm_systolic_ga() : sa_warm_systolic_sw();
+	return e != hipSuccess ? e : sa_warm_generic();
+}

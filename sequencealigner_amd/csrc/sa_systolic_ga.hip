@@ -2,4 +2,5 @@
 #include "sa_internal.h"
 #define SA_SYS_METHOD SA_METHOD_GA
 #define SA_SYS_LAUNCH sa_launch_systolic_ga
+#define SA_SYS_WARM sa_warm_systolic_ga
 #include "sa_systolic_kernel.inc"

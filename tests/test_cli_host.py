@@ -129,3 +129,48 @@ def test_hdf5_equals_reference_writer(host, tmp_path, amino_lut, sa, oracle, n, 
         assert props(ref_path) == props(mine)
     finally:
         ref.close()
+
+
+def test_matrix_allocator_file_backed_branch(host, tmp_path, monkeypatch):
+    """output_load's temporary-file storage (reference src/io/output.c:36-55, src/system/os.c:112-125): once the full
+    matrix exceeds 3/4 of MemAvailable the (triangular) matrix is a MAP_SHARED mapping of an unnamed file.  The
+    threshold is forced through SA_HOST_MEM_AVAILABLE."""
+    import ctypes as C
+    lib = host.lib
+    lib.sa_host_matrix_alloc.argtypes = [C.c_size_t, C.c_bool, C.c_bool]
+    lib.sa_host_matrix_alloc.restype = C.POINTER(C.c_int32)
+    lib.sa_host_matrix_free.argtypes = [C.POINTER(C.c_int32), C.c_size_t, C.c_bool]
+    lib.sa_host_matrix_needs_file.argtypes = [C.c_size_t]
+    lib.sa_host_matrix_needs_file.restype = C.c_bool
+    lib.sa_host_available_memory.restype = C.c_size_t
+    n = 300
+    assert lib.sa_host_available_memory() > 0 and not lib.sa_host_matrix_needs_file(n)
+    monkeypatch.setenv("SA_HOST_MEM_AVAILABLE", str(4 * n * n))  # full matrix = 4/3 of "3/4 of available"
+    assert lib.sa_host_available_memory() == 4 * n * n and lib.sa_host_matrix_needs_file(n)
+    monkeypatch.setenv("SA_HOST_MEM_AVAILABLE", str(2 * 4 * n * n))
+    assert not lib.sa_host_matrix_needs_file(n)
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+
+    def mapping_of(addr):
+        for line in open("/proc/self/maps"):
+            lo, hi = (int(x, 16) for x in line.split()[0].split("-"))
+            if lo <= addr < hi:
+                return line
+        return ""
+
+    for file_backed in (False, True):
+        m = lib.sa_host_matrix_alloc(n, True, file_backed)
+        assert m, host._err()
+        elems = n * (n - 1) // 2
+        arr = np.ctypeslib.as_array(m, shape=(elems,))
+        assert not arr.any()  # zero-filled like the anonymous mapping: the diagonal is never written (output.c:76-81)
+        arr[:] = np.arange(elems, dtype=np.int32)
+        assert int(arr[-1]) == elems - 1
+        line = mapping_of(C.addressof(m.contents))
+        if file_backed:  # a shared mapping of a deleted (unnamed) file under $TMPDIR
+            assert " rw-s " in line and str(tmp_path) in line and "(deleted)" in line, line
+        else:
+            assert " rw-p " in line and str(tmp_path) not in line, line
+        del arr
+        lib.sa_host_matrix_free(m, n, True)
+    assert list(tmp_path.iterdir()) == []  # nothing left behind

@@ -1,0 +1,96 @@
+"""GPU (-m gpu): sa_ctx_align_host -- the launch/copy loop of cuda_align (reference src/interface/seqalign_cuda.c:182-292)
+on a ready context -- against the oracle: packed and full destinations, page-locked and pageable, sub-ranges,
+the shell schedule of the full layout and its host-scatter fallback, -W (no destination), several devices."""
+import numpy as np
+import pytest
+
+from tests.golden_util import tri_to_full
+from tests.synth import make_dna_set, make_protein_set
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("nw", "blosum62", dict(gap_pen=4)), ("ga", "blosum62", dict(gap_open=10, gap_extend=1)),
+         ("sw", "blosum62", dict(gap_open=10, gap_extend=1))]
+
+
+def tri(j):
+    return j * (j - 1) // 2
+
+
+@pytest.mark.parametrize("method,matrix,gaps", CASES)
+def test_packed_and_full_delivery_match_oracle(method, matrix, gaps, sa, oracle):
+    seqs = make_protein_set(900, 20, 170, 31)  # 404 550 pairs: several shrinking batches would need > 3 Mi; see below
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(method, matrix, **gaps)
+    want = oracle.align(store, scoring, triangular=True)
+    n = store.num
+    with sa.Context(store, scoring, 0) as ctx:
+        for pinned in (True, False):
+            dest = sa.PinnedMatrix(store.pairs) if pinned else None
+            arr = dest.array if pinned else np.zeros(store.pairs, np.int32)
+            phase = ctx.align_host(arr, triangular=True)
+            assert phase > 0 and np.array_equal(arr, want)
+            arr[:] = -7  # a sub-range touches nothing outside it
+            lo, cnt = 12345, 200000
+            ctx.align_host(arr, triangular=True, start=lo, count=cnt)
+            assert np.array_equal(arr[lo:lo + cnt], want[lo:lo + cnt]) and (arr[:lo] == -7).all() and (arr[lo + cnt:] == -7).all()
+            if dest is not None:
+                dest.close()
+        full = np.full(n * n, -1, np.int32)
+        ctx.align_host(full, triangular=False)  # shell schedule: diagonal written as 0
+        assert np.array_equal(full.reshape(n, n), tri_to_full(want, n))
+        # a column-aligned slice of the full layout (what one device of several delivers): only its shell is written
+        ja, jb = 300, 701
+        full[:] = -1
+        ctx.align_host(full, triangular=False, start=tri(ja), count=tri(jb) - tri(ja))
+        f = full.reshape(n, n)
+        ref = tri_to_full(want, n)
+        shell = np.zeros((n, n), bool)
+        shell[ja:jb, :jb] = True
+        shell[:ja, ja:jb] = True
+        assert np.array_equal(f[shell], ref[shell]) and (f[~shell] == -1).all()
+        # a range that is not column-aligned: staged batches scattered by the host (output_fill order)
+        full[:] = 0
+        lo, cnt = 1000, 300001
+        ctx.align_host(full, triangular=False, start=lo, count=cnt)
+        part = np.zeros(store.pairs, np.int32)
+        part[lo:lo + cnt] = want[lo:lo + cnt]
+        assert np.array_equal(full.reshape(n, n), tri_to_full(part, n))
+        assert ctx.align_host(None, triangular=True) > 0  # -W: compute, copy nothing
+
+
+def test_many_shrinking_batches_and_shell_fallback(sa, oracle, monkeypatch):
+    """8 M pairs: the delivery loop runs several geometrically shrinking batches (packed) / column shells (full);
+    SA_HIP_NO_SHELLS forces the full layout through the host-scatter path."""
+    seqs = make_dna_set(4000, 8, 24, 77)
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names("sw", "nuc44", gap_open=10, gap_extend=1)
+    want = oracle.align(store, scoring, triangular=True, threads=16)
+    n = store.num
+    with sa.Context(store, scoring, 0) as ctx:
+        arr = np.zeros(store.pairs, np.int32)
+        ctx.align_host(arr, triangular=True)
+        assert np.array_equal(arr, want)
+        full = np.full(n * n, -1, np.int32)
+        ctx.align_host(full, triangular=False)
+        assert np.array_equal(full.reshape(n, n), tri_to_full(want, n))
+    monkeypatch.setenv("SA_HIP_NO_SHELLS", "1")
+    with sa.Context(store, scoring, 0) as ctx:
+        full = np.zeros(n * n, np.int32)
+        ctx.align_host(full, triangular=False)
+        assert np.array_equal(full.reshape(n, n), tri_to_full(want, n))
+
+
+def test_two_physical_devices_when_visible(sa, oracle):
+    """sa_hip_align over >= 2 hipSetDevice targets (one host thread and one context per device, each delivering its
+    slice / its column shells straight into the host matrix).  One-GPU boxes skip; SA_HIP_SPLIT covers the same code
+    with every slice folded onto device 0 (test_gpu_parity.py::test_multi_device_driver_path)."""
+    if sa.device_count() < 2:
+        pytest.skip("needs two visible devices")
+    store = sa.SequenceStore.from_sequences(make_protein_set(1500, 30, 200, 5))
+    for method, matrix, gaps in CASES:
+        scoring = sa.Scoring.from_names(method, matrix, **gaps)
+        want = oracle.align(store, scoring, triangular=True, threads=16)
+        assert np.array_equal(sa.hip_align(store, scoring, triangular=True), want)
+        assert np.array_equal(sa.hip_align(store, scoring, triangular=False), tri_to_full(want, store.num))
+    assert sa.hip_memory(1 << 20)

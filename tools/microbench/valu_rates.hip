@@ -70,11 +70,24 @@ template <int MODE> __global__ __launch_bounds__(256) void k(int *out, unsigned 
 
 static int *g_out; static unsigned long long *g_cyc, *g_rt;
 
+/* calibration accumulators: s_memtime ticks, s_memrealtime ticks and host-timed nanoseconds of the same kernels */
+static double g_ticks, g_rticks, g_wall_ns;
+
 template <int MODE> int run(const char *name, int bpc)
 {
 	const int blocks = 256 * bpc;
-	for (int it = 0; it < 2; it++) hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, g_out, g_cyc, g_rt, 3);
+	hipEvent_t e0, e1;
+	CHECK(hipEventCreate(&e0));
+	CHECK(hipEventCreate(&e1));
+	hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, g_out, g_cyc, g_rt, 3); /* warm */
+	CHECK(hipEventRecord(e0, 0));
+	hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, g_out, g_cyc, g_rt, 3);
+	CHECK(hipEventRecord(e1, 0));
 	CHECK(hipDeviceSynchronize());
+	float ms = 0.f;
+	CHECK(hipEventElapsedTime(&ms, e0, e1));
+	(void)hipEventDestroy(e0);
+	(void)hipEventDestroy(e1);
 	std::vector<unsigned long long> hc(blocks * 4), hr(blocks * 4);
 	CHECK(hipMemcpy(hc.data(), g_cyc, 8 * hc.size(), hipMemcpyDeviceToHost));
 	CHECK(hipMemcpy(hr.data(), g_rt, 8 * hr.size(), hipMemcpyDeviceToHost));
@@ -82,7 +95,11 @@ template <int MODE> int run(const char *name, int bpc)
 	for (size_t i = 0; i < hc.size(); i++) { c += hc[i]; r += hr[i]; }
 	c /= hc.size(); r /= hr.size();
 	const double insts = (double)REP * 4 * 8;
-	printf("  %-26s %5.2f", name, c / insts / bpc);
+	/* wall: every SIMD executes insts*bpc wave-instructions during the launch (all blocks co-resident: 256 CUs x bpc
+	 * blocks, one wave per SIMD each); the launch also contains ~10 us of ramp, visible as wall > ticks/clock */
+	printf("  %5.2f (%5.3f ns)", c / insts / bpc, (double)ms * 1e6 / (insts * bpc));
+	g_ticks += c; g_rticks += r; g_wall_ns += (double)ms * 1e6;
+	(void)name;
 	return 0;
 }
 
@@ -93,7 +110,7 @@ int main()
 	CHECK(hipMalloc(&g_out, sizeof(int) * 256 * 8 * 256));
 	CHECK(hipMalloc(&g_cyc, 8 * 256 * 8 * 4));
 	CHECK(hipMalloc(&g_rt, 8 * 256 * 8 * 4));
-	printf("SIMD cycles (s_memtime ticks) per wave64 instruction, all waves of the SIMD together; columns = 1,2,4,8 waves/SIMD");
+	printf("Per wave64 instruction, all waves of the SIMD together: s_memtime ticks (host-timed ns of the whole launch per instruction); columns = 1,2,4,8 waves/SIMD");
 	ROW(0, "v_add_u32_e32"); ROW(22, "v_add_u32_e64"); ROW(10, "v_sub_u32_e32"); ROW(28, "v_add_co_u32_e32");
 	ROW(9, "v_and_b32"); ROW(26, "v_or_b32"); ROW(27, "v_xor_b32"); ROW(33, "v_mov_b32");
 	ROW(4, "v_max_i32_e32"); ROW(21, "v_max_i32_e64"); ROW(23, "v_max_i32 inline const"); ROW(25, "v_min_i32"); ROW(5, "v_max_u32");
@@ -102,6 +119,11 @@ int main()
 	ROW(1, "v_add_u32_sdwa"); ROW(18, "v_add_u32_dpp"); ROW(3, "v_mov_b32_dpp"); ROW(11, "v_cndmask_b32");
 	ROW(16, "v_pk_add_i16"); ROW(17, "v_pk_max_i16"); ROW(32, "v_pk_max_f16"); ROW(19, "v_cvt_f32_ubyte1"); ROW(20, "v_dot4c_i32_i8");
 	ROW(34, "v_bfe_i32"); ROW(35, "v_perm_b32");
-	printf("\n");
+	printf("\n\ncalibration over all launches above: s_memtime %.1f ticks/us of s_memrealtime (100 MHz) = %.0f MHz;  "
+	       "s_memtime %.1f ticks per host-timed us (includes launch ramp, lower bound of the clock);  "
+	       "=> one s_memtime tick is one shader clock at the frequency the chip held (~%.2f GHz), "
+	       "a column entry of 2.00 ticks = %.3f ns per wave64 instruction and SIMD\n",
+	       g_ticks / g_rticks * 100.0, g_ticks / g_rticks * 100.0, g_ticks / (g_wall_ns * 1e-3),
+	       g_ticks / g_rticks * 0.1, 2.0 / (g_ticks / g_rticks * 0.1));
 	return 0;
 }

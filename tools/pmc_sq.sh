@@ -2,7 +2,7 @@
 # SQ counter passes over a short bench run (development helper; run through gpurun)
 TAG=${1:-x}; shift
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $@"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-host-boundary --no-extra --device-resident-only $@"
 cd /tmp
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p1 -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/p1.err || tail -3 $OUT/p1.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_LDS_UNALIGNED_STALL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d $OUT/p2 -- python3 $ROOT/bench.py $ARGS > /dev/null 2> $OUT/p2.err || tail -3 $OUT/p2.err

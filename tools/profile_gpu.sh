@@ -7,7 +7,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-host-boundary $@"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-host-boundary --no-extra --device-resident-only $@"
 python3 bench.py --steps 3 --warmup 1 "$@" > $OUT/bench.json 2> $OUT/bench.err || { tail -5 $OUT/bench.err; exit 1; }
 cat $OUT/bench.json
 cd /tmp
