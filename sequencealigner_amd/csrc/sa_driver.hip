@@ -39,7 +39,7 @@ struct sa_ctx {
 	/* tile counters of the persistent launches: one slot of (classes + 1) counters per sa_ctx_align_range
 	 * call, taken round-robin from a ring so that ranges issued back to back on DIFFERENT streams (an
 	 * overlapped multi-chunk schedule) never share a counter */
-	enum { COUNTER_SLOTS = 256, COUNTERS_PER_SLOT = SA_SYS_NCLASSES + 1 };
+	enum { COUNTER_SLOTS = 256, COUNTERS_PER_SLOT = SA_PLAN_NCLASSES };
 	unsigned *d_counters = nullptr;
 	uint64_t call_no = 0;
 	hipEvent_t slot_done[COUNTER_SLOTS] = {}; /* recorded after the launches that used a slot: its next user waits */
@@ -55,6 +55,10 @@ struct sa_ctx {
 	bool sys_ok = false;
 	int32_t sys_pconst = 0, sys_q = 0;
 	int64_t sys_gain = 0, sys_slack = 0;
+	/* packed-u16 kernels (sa_systolic_pk.inc): column classes K = 1..pk_kmax run there (0: none), see pk_setup */
+	int pk_kmax = 0;
+	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0;
+	int64_t pk_gain = 0, pk_slack = 0;
 	/* launch plans of recently used packed ranges (callers loop over the same few ranges) */
 	struct ClassLaunch {
 		int cls = 0;
@@ -291,6 +295,65 @@ static int systolic_class_for(int32_t n)
 	return SA_SYS_CLASS_LONG;
 }
 
+/* frame shifts a value of the packed kernels can see before its last use: its own terminator entering the group plus
+ * one per later terminator entering while its last rows travel through the remaining G - 1 = 7 lanes (terminators are
+ * at least two stream positions apart) */
+constexpr int PK_LIVE = 4;
+
+static int32_t pk_delta(const sa_ctx *ctx, int k) { return (int32_t)(ctx->pk_gain * 8 * k + ctx->pk_slack); }
+static int32_t pk_base(const sa_ctx *ctx, int k)
+{
+	return PK_LIVE * pk_delta(ctx, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4; /* (Gotoh: values reach BASE + 3q) */
+}
+
+/* Decides which column classes the packed-u16 kernels reproduce exactly (see sa_systolic_pk.inc): profile entries
+ * S + const (and the Gotoh first-column tweak) are >= 0, Gotoh q <= 0, and for class K every value of a register stays
+ * inside [floor, 65535]: BASE + DELTA + the largest profile entry must fit.  The largest such K is pk_kmax. */
+static void pk_setup(sa_ctx *ctx)
+{
+	const sa_scoring &sc = ctx->sc;
+	ctx->pk_kmax = 0;
+	if (!ctx->sys_ok || getenv("SA_HIP_NO_PK") || (sc.method != SA_METHOD_NW && sc.method != SA_METHOD_GA))
+		return;
+	int64_t smax = INT32_MIN, smin = INT32_MAX;
+	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++) {
+		smax = std::max<int64_t>(smax, sc.sub[k]);
+		smin = std::min<int64_t>(smin, sc.sub[k]);
+	}
+	const int64_t g = sc.gap_pen, o = sc.gap_opn, e = sc.gap_ext;
+	int64_t pconst, q = 0, pmax, gain, slack, floor_v;
+	if (sc.method == SA_METHOD_NW) {
+		pconst = -2 * g;
+		pmax = smax + pconst;
+		gain = std::max<int64_t>(1, pmax);
+		slack = 2;
+		floor_v = 0;
+	} else {
+		q = o - e;
+		if (q > 0)
+			return;
+		pconst = -e - o;
+		pmax = smax + pconst - q; /* the first real column carries -q on top */
+		gain = std::max<int64_t>(1, smax - 2 * e);
+		slack = 2 * (-q) + 2;
+		floor_v = 2 * (-q) + 2;
+	}
+	if (smin + pconst < 0 || pmax > 4096 || -q > 4096)
+		return;
+	ctx->pk_pconst = (int32_t)pconst;
+	ctx->pk_q = (int32_t)q;
+	ctx->pk_gain = gain;
+	ctx->pk_slack = slack;
+	ctx->pk_floor = (int32_t)floor_v;
+	for (int k = 1; k <= SA_PK_KMAX; k++) {
+		const int64_t delta = gain * 8 * k + slack;
+		const int64_t top = (PK_LIVE + 1) * delta + floor_v + 4 * (-q) + 4 + pmax + (-q);
+		if (top > 65535)
+			break;
+		ctx->pk_kmax = k;
+	}
+}
+
 extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa_scoring *sc)
 {
 	if (!sc) {
@@ -323,6 +386,7 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	if (const char *e = getenv("SA_HIP_CHUNK")) /* development switch: fixed stream length */
 		ctx->env_chunk = std::max(1, std::min(SA_SYS_CHUNK, atoi(e)));
 	systolic_setup(ctx);
+	pk_setup(ctx);
 	int8_t sub8[SA_SUB_DIM * SA_SUB_DIM];
 	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++)
 		sub8[k] = (int8_t)std::max(-128, std::min(127, sc->sub[k]));
@@ -570,8 +634,9 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 	}
 	ctx->plan = nullptr;
 	const int64_t end = start + count;
-	std::vector<std::vector<int32_t>> jl((size_t)SA_SYS_NCLASSES + 1), tp((size_t)SA_SYS_NCLASSES + 1);
-	std::vector<int64_t> cpairs((size_t)SA_SYS_NCLASSES + 1, 0), ccells((size_t)SA_SYS_NCLASSES + 1, 0);
+	std::vector<std::vector<int32_t>> jl((size_t)SA_PLAN_NCLASSES), tp((size_t)SA_PLAN_NCLASSES);
+	std::vector<int64_t> cpairs((size_t)SA_PLAN_NCLASSES, 0), ccells((size_t)SA_PLAN_NCLASSES, 0);
+	std::vector<std::vector<std::pair<int32_t, int32_t>>> rows_of((size_t)SA_PLAN_NCLASSES); /* packed classes: [ia, ib) per column */
 	std::vector<int64_t> lenpre((size_t)ctx->num + 1, 0);
 	for (int32_t k = 0; k < ctx->num; k++)
 		lenpre[(size_t)k + 1] = lenpre[(size_t)k] + ctx->meta[(size_t)k].len;
@@ -595,6 +660,14 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		if (ib <= ia)
 			continue;
 		const int32_t n = ctx->meta[(size_t)j].len;
+		if ((n + 7) / 8 <= ctx->pk_kmax) { /* packed-u16 class K = ceil(n / 8): tiles are counted per column PAIR below */
+			const size_t pc = (size_t)(SA_PK_CLASS0 + (n + 7) / 8);
+			jl[pc].push_back(j);
+			rows_of[pc].emplace_back((int32_t)ia, (int32_t)ib);
+			cpairs[pc] += ib - ia;
+			ccells[pc] += (int64_t)n * (lenpre[(size_t)ib] - lenpre[(size_t)ia]);
+			continue;
+		}
 		const int cls = ctx->sys_ok ? systolic_class_for(n) : -1;
 		if (cls < 0) {
 			if (!plan.generic.empty() && plan.generic.back().first + plan.generic.back().second == tri + ia)
@@ -618,8 +691,27 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		cpairs[(size_t)cls] += ib - ia;
 		ccells[(size_t)cls] += (int64_t)n * (lenpre[(size_t)ib] - lenpre[(size_t)ia]);
 	}
+	/* packed classes: consecutive columns of a class share a tile (sa_systolic_pk.inc): rows = the union of their row
+	 * ranges, SA_PK_WPB * 8 streams of `chunk` sequences per workgroup-tile */
+	for (int cls = SA_PK_CLASS0; cls < SA_PLAN_NCLASSES; cls++) {
+		const auto &rw = rows_of[(size_t)cls];
+		if (rw.empty())
+			continue;
+		const int64_t rows = (int64_t)SA_PK_WPB * 8 * plan.chunk;
+		tp[(size_t)cls].push_back(0);
+		for (size_t c = 0; c < rw.size(); c += 2) {
+			const auto &a = rw[c], &b = rw[c + 1 < rw.size() ? c + 1 : c];
+			const int64_t span = std::max(a.second, b.second) - std::min(a.first, b.first);
+			const int64_t tiles = (span + rows - 1) / rows;
+			if ((int64_t)tp[(size_t)cls].back() + tiles > INT32_MAX) {
+				sa_set_error("packed range too large for one launch; split it into smaller ranges");
+				return false;
+			}
+			tp[(size_t)cls].push_back(tp[(size_t)cls].back() + (int32_t)tiles);
+		}
+	}
 	bool ok = true;
-	for (int cls = 0; cls <= SA_SYS_NCLASSES && ok; cls++) {
+	for (int cls = 0; cls < SA_PLAN_NCLASSES && ok; cls++) {
 		if (jl[(size_t)cls].empty())
 			continue;
 		sa_ctx::ClassLaunch cl;
@@ -755,8 +847,10 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			s = ctx->side[side_k];
 			SA_HIP_CHECK(hipStreamWaitEvent(s, ctx->fork_ev, 0), return 1);
 		}
+		const bool is_pk = cl.cls >= SA_PK_CLASS0;
+		const int pk_k = cl.cls - SA_PK_CLASS0;
 		const bool is_long = cl.cls == SA_SYS_CLASS_LONG;
-		const int64_t W = is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
+		const int64_t W = is_pk ? 8 * pk_k : is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
 					  : SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
 		SaSysArgs a{};
 		a.codes = ctx->d_codes;
@@ -776,6 +870,13 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		a.gap_o = ctx->sc.gap_opn;
 		a.gap_e = ctx->sc.gap_ext;
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
+		if (is_pk) {
+			a.pconst = ctx->pk_pconst;
+			a.q = ctx->pk_q;
+			a.delta = pk_delta(ctx, pk_k);
+			a.pk_base = pk_base(ctx, pk_k);
+			a.pk_floor = ctx->pk_floor;
+		}
 		a.counter = counters + cl.cls;
 		a.chunk = is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
 		if (is_long) {
@@ -792,7 +893,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.long_stride = ctx->long_stride;
 		}
 		char name[64];
-		if (is_long)
+		if (is_pk)
+			snprintf(name, sizeof(name), "sa_k_systolic_pk<%s,K%d>", METHOD_TAG[ctx->sc.method], pk_k);
+		else if (is_long)
 			snprintf(name, sizeof(name), "sa_k_systolic<%s,G64,K16,strips>", METHOD_TAG[ctx->sc.method]);
 		else
 			snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
@@ -800,16 +903,20 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
 		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
 		unsigned long long *d_stamps = nullptr;
-		if (ctx->env_stamps) {
+		if (ctx->env_stamps && !is_pk) {
 			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
 			a.stamps = d_stamps;
 		}
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
-		const int wgs = (int)std::min<int64_t>(is_long ? ctx->long_wgs : ctx->persistent_wgs,
+		const int wgs = (int)std::min<int64_t>(is_pk ? ctx->persistent_wgs / 4 : is_long ? ctx->long_wgs : ctx->persistent_wgs,
 						       cl.ntiles);
-		SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
+		if (is_pk) {
+			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pk_k, a, wgs, s), return 1);
+		} else {
+			SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
+		}
 		if (d_stamps) {
 			std::vector<unsigned long long> h(3 * (size_t)cl.ntiles);
 			SA_HIP_CHECK(hipStreamSynchronize(s), return 1);

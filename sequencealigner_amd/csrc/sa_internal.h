@@ -76,6 +76,16 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 	     SA_SYS_CLASS_LONG = SA_SYS_NCLASSES, /* strip-mined launch of the widest class (G=64, K=16) */
 	     SA_SYS_LONG_W = 1024 };
 
+/* packed-u16 kernels (sa_systolic_pk.inc): 8-lane groups, K = 1..SA_PK_KMAX columns per lane (W = 8 K <= 192), two
+ * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
+#define SA_PK_WPB 2
+#define SA_PK_KMAX 24
+#define SA_PK_K_LIST(X) \
+	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
+	X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+/* class index space of a plan: [0, SA_SYS_NCLASSES) s32 classes, SA_SYS_CLASS_LONG, then SA_PK_CLASS0 + K */
+enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PLAN_NCLASSES = SA_PK_CLASS0 + SA_PK_KMAX + 1 };
+
 struct SaSysArgs {
 	const uint8_t *codes;    /* encoded store, tight layout: sequence k at off[k], terminator after it */
 	const int32_t *off;      /* num+1 offsets; len_k = off[k+1]-off[k]-1                              */
@@ -93,6 +103,8 @@ struct SaSysArgs {
 	int32_t chunk;           /* sequences per group stream of a wave-tile, 1..SA_SYS_CHUNK            */
 	int32_t *long_scratch;   /* strip-mined launch: per wave 2 lines of long_stride/2 ints            */
 	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
+	int32_t pk_base;         /* packed kernels: the constant baseline BASE and the lowest value a register may hold */
+	int32_t pk_floor;
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
@@ -100,6 +112,8 @@ struct SaSysArgs {
 
 /* `workgroups` persistent workgroups pull the launch's wave-tiles from a.counter */
 hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workgroups, hipStream_t s);
+/* packed-u16 kernels: class K of SA_PK_K_LIST; jlist holds the columns, tprefix the tiles before each column PAIR */
+hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int workgroups, hipStream_t s);
 /* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */
 hipError_t sa_warm_kernels(int method);
 

@@ -19,6 +19,23 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 	}
 }
 
+hipError_t sa_launch_systolic_pk_nw(int k, const SaSysArgs &a, int tiles, hipStream_t s);
+hipError_t sa_launch_systolic_pk_ga(int k, const SaSysArgs &a, int tiles, hipStream_t s);
+
+hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int tiles, hipStream_t s)
+{
+	switch (method) {
+	case SA_METHOD_NW:
+		return sa_launch_systolic_pk_nw(k, a, tiles, s);
+	case SA_METHOD_GA:
+		return sa_launch_systolic_pk_ga(k, a, tiles, s);
+	default:
+		return hipErrorInvalidValue;
+	}
+}
+
+hipError_t sa_warm_systolic_pk_nw(void);
+hipError_t sa_warm_systolic_pk_ga(void);
 hipError_t sa_warm_systolic_nw(void);
 hipError_t sa_warm_systolic_ga(void);
 hipError_t sa_warm_systolic_sw(void);
@@ -27,5 +44,9 @@ hipError_t sa_warm_generic(void);
 hipError_t sa_warm_kernels(int method)
 {
 	hipError_t e = method == SA_METHOD_NW ? sa_warm_systolic_nw() : method == SA_METHOD_GA ? sa_warm_systolic_ga() : sa_warm_systolic_sw();
+	if (e == hipSuccess && method == SA_METHOD_NW)
+		e = sa_warm_systolic_pk_nw();
+	if (e == hipSuccess && method == SA_METHOD_GA)
+		e = sa_warm_systolic_pk_ga();
 	return e != hipSuccess ? e : sa_warm_generic();
 }
