@@ -78,7 +78,7 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 
 /* packed-u16 kernels (sa_systolic_pk.inc): 8-lane groups, K = 1..SA_PK_KMAX columns per lane (W = 8 K <= 192), two
  * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
-#define SA_PK_WPB 2
+#define SA_PK_WPB 4
 #define SA_PK_KMAX 24
 #define SA_PK_K_LIST(X) \
 	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
