@@ -58,7 +58,7 @@ struct sa_ctx {
 	/* packed-u16 kernels (sa_systolic_pk.inc): column classes K = 1..pk_kmax run there (0: none), see pk_setup */
 	int pk_kmax = 0;
 	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0;
-	int64_t pk_gain = 0, pk_slack = 0;
+	int64_t pk_gain = 0, pk_slack = 0, pk_extra = 0;
 	/* launch plans of recently used packed ranges (callers loop over the same few ranges) */
 	struct ClassLaunch {
 		int cls = 0;
@@ -303,7 +303,9 @@ constexpr int PK_LIVE = 4;
 static int32_t pk_delta(const sa_ctx *ctx, int k) { return (int32_t)(ctx->pk_gain * 8 * k + ctx->pk_slack); }
 static int32_t pk_base(const sa_ctx *ctx, int k)
 {
-	return PK_LIVE * pk_delta(ctx, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4; /* (Gotoh: values reach BASE + 3q) */
+	/* (Gotoh: values reach BASE + 3q; SW: the lanes start up to 8 |e| below the baseline) */
+	return PK_LIVE * pk_delta(ctx, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4 +
+	       (ctx->sc.method == SA_METHOD_SW ? 8 * std::abs(ctx->sc.gap_ext) : 0);
 }
 
 /* Decides which column classes the packed-u16 kernels reproduce exactly (see sa_systolic_pk.inc): profile entries
@@ -313,7 +315,7 @@ static void pk_setup(sa_ctx *ctx)
 {
 	const sa_scoring &sc = ctx->sc;
 	ctx->pk_kmax = 0;
-	if (!ctx->sys_ok || getenv("SA_HIP_NO_PK") || (sc.method != SA_METHOD_NW && sc.method != SA_METHOD_GA))
+	if (!ctx->sys_ok || getenv("SA_HIP_NO_PK"))
 		return;
 	int64_t smax = INT32_MIN, smin = INT32_MAX;
 	for (int k = 0; k < SA_SUB_DIM * SA_SUB_DIM; k++) {
@@ -321,8 +323,20 @@ static void pk_setup(sa_ctx *ctx)
 		smin = std::min<int64_t>(smin, sc.sub[k]);
 	}
 	const int64_t g = sc.gap_pen, o = sc.gap_opn, e = sc.gap_ext;
-	int64_t pconst, q = 0, pmax, gain, slack, floor_v;
-	if (sc.method == SA_METHOD_NW) {
+	int64_t pconst, q = 0, pmax, gain, slack, floor_v, extra = 0;
+	if (sc.method == SA_METHOD_SW) {
+		/* row-shifted domain: V = m - |o - e| and X = max(V, X) - |e| are plain subtractions (o <= e <= 0), values drift
+		 * up by |e| per stream position of a tile and the lanes start up to G |e| below the baseline */
+		if (o > e)
+			return;
+		pconst = -o;
+		pmax = smax + pconst;
+		gain = std::max<int64_t>(1, smax);
+		slack = -o - e + 2;
+		floor_v = -o - 2 * e + 2;
+		q = o + e; /* (only its magnitude is used below: margins) */
+		extra = (int64_t)SA_SYS_CHUNK * ((int64_t)ctx->max_len + 1) * (-e) + 8 * (-e);
+	} else if (sc.method == SA_METHOD_NW) {
 		pconst = -2 * g;
 		pmax = smax + pconst;
 		gain = std::max<int64_t>(1, pmax);
@@ -342,12 +356,13 @@ static void pk_setup(sa_ctx *ctx)
 		return;
 	ctx->pk_pconst = (int32_t)pconst;
 	ctx->pk_q = (int32_t)q;
+	ctx->pk_extra = extra;
 	ctx->pk_gain = gain;
 	ctx->pk_slack = slack;
 	ctx->pk_floor = (int32_t)floor_v;
 	for (int k = 1; k <= SA_PK_KMAX; k++) {
 		const int64_t delta = gain * 8 * k + slack;
-		const int64_t top = (PK_LIVE + 1) * delta + floor_v + 4 * (-q) + 4 + pmax + (-q);
+		const int64_t top = (PK_LIVE + 1) * delta + floor_v + 4 * (-q) + 4 + pmax + (-q) + extra;
 		if (top > 65535)
 			break;
 		ctx->pk_kmax = k;
@@ -872,7 +887,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
 		if (is_pk) {
 			a.pconst = ctx->pk_pconst;
-			a.q = ctx->pk_q;
+			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
 			a.delta = pk_delta(ctx, pk_k);
 			a.pk_base = pk_base(ctx, pk_k);
 			a.pk_floor = ctx->pk_floor;

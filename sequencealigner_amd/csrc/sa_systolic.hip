@@ -21,6 +21,7 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 
 hipError_t sa_launch_systolic_pk_nw(int k, const SaSysArgs &a, int tiles, hipStream_t s);
 hipError_t sa_launch_systolic_pk_ga(int k, const SaSysArgs &a, int tiles, hipStream_t s);
+hipError_t sa_launch_systolic_pk_sw(int k, const SaSysArgs &a, int tiles, hipStream_t s);
 
 hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int tiles, hipStream_t s)
 {
@@ -29,6 +30,8 @@ hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int tile
 		return sa_launch_systolic_pk_nw(k, a, tiles, s);
 	case SA_METHOD_GA:
 		return sa_launch_systolic_pk_ga(k, a, tiles, s);
+	case SA_METHOD_SW:
+		return sa_launch_systolic_pk_sw(k, a, tiles, s);
 	default:
 		return hipErrorInvalidValue;
 	}
@@ -36,6 +39,7 @@ hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int tile
 
 hipError_t sa_warm_systolic_pk_nw(void);
 hipError_t sa_warm_systolic_pk_ga(void);
+hipError_t sa_warm_systolic_pk_sw(void);
 hipError_t sa_warm_systolic_nw(void);
 hipError_t sa_warm_systolic_ga(void);
 hipError_t sa_warm_systolic_sw(void);
@@ -48,5 +52,7 @@ hipError_t sa_warm_kernels(int method)
 		e = sa_warm_systolic_pk_nw();
 	if (e == hipSuccess && method == SA_METHOD_GA)
 		e = sa_warm_systolic_pk_ga();
+	if (e == hipSuccess && method == SA_METHOD_SW)
+		e = sa_warm_systolic_pk_sw();
 	return e != hipSuccess ? e : sa_warm_generic();
 }
