@@ -44,11 +44,14 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 s32 lane-ops/s
 OPS_PER_CELL = {"nw": 5, "ga": 9, "sw": 11}  # reference op counts (nw.c:29-35, ga.c:47-62, sw.c:39-57)
-# wave64 VALU instructions one DP cell costs at the very least with this kernel's formulation times
-# the guide's 2 SIMD cycles per wave64 instruction (MI355X_MICROARCH.md, v_fma_f32 row; calibration of the
-# microbenchmarks against wall clock: profiles/r02_microbench_valu_rates.txt)
-MIN_INSTS_PER_CELL = {"nw": 2, "ga": 5, "sw": 6.5}
-CYCLES_PER_WAVE64_INST = 2.0
+# SIMD issue cycles one wave64 DP cell costs at the very least with the packed-u16 formulation: per TWO
+# cells NW = 1 plain 32-bit add + 2 v_pk_max_u16, Gotoh = 2 + 4, SW = 3 + 6.  Instruction costs measured on this chip
+# with long kernels against the wall clock (profiles/r02_microbench_nw_chain_dependency_shapes.txt,
+# r02_microbench_valu_rates_wallclock.txt): VOP3 / VOP3P / SDWA / DPP ~4.1 SIMD cycles per wave64 instruction, plain
+# 32-bit VOP2 ~2.5 -- the guide's "2 cycles" row is the plain-VOP2 / v_fma_f32 class.
+CYC_SLOW, CYC_FAST = 4.1, 2.5
+MIN_ISSUE_CYCLES_PER_CELL = {"nw": (1 * CYC_FAST + 2 * CYC_SLOW) / 2, "ga": (2 * CYC_FAST + 4 * CYC_SLOW) / 2,
+                             "sw": (3 * CYC_FAST + 6 * CYC_SLOW) / 2}
 SIMDS, SHADER_HZ = 256 * 4, 2.4e9
 CFG4_SHAPE_N = 12_000  # "cfg4 shape": the cfg4 generator and scoring at a size one GPU finishes in a fraction of a second
 
@@ -158,9 +161,10 @@ def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_siz
 def valu_of(method: str, cells: int, seconds: float) -> dict:
     gcups = cells / seconds / 1e9
     return {"gcups_this_rank": gcups, "reference_ops_per_cell": OPS_PER_CELL[method],
-            "min_wave64_insts_per_cell": MIN_INSTS_PER_CELL[method], "cycles_per_wave64_inst": CYCLES_PER_WAVE64_INST,
-            # wave-cells x (minimal instructions per cell x 2 cycles) / SIMD cycles available in the step
-            "frac_of_valu_issue_bound": (cells / 64) * MIN_INSTS_PER_CELL[method] * CYCLES_PER_WAVE64_INST / (seconds * SIMDS * SHADER_HZ)}
+            "min_issue_cycles_per_wave_cell": MIN_ISSUE_CYCLES_PER_CELL[method],
+            "cycles_per_wave64_inst": {"vop3_vop3p_sdwa_dpp": CYC_SLOW, "plain_vop2": CYC_FAST},
+            # wave-cells x minimal issue cycles per cell / SIMD cycles available in the step (1024 SIMDs at 2.4 GHz)
+            "frac_of_valu_issue_bound": (cells / 64) * MIN_ISSUE_CYCLES_PER_CELL[method] / (seconds * SIMDS * SHADER_HZ)}
 
 
 def time_host_steps(ctx, dest, steps: int, warmup: int, torch) -> tuple[float, dict]:

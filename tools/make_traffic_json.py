@@ -16,9 +16,13 @@ def collect(sub):
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             m = re.search(r"sa_k_systolic<(\d), (\d+), (\d+), (true|false)>", r["Kernel_Name"])
-            if not m:
+            mp = re.search(r"sa_k_systolic_pk<(\d), (\d+)>", r["Kernel_Name"])
+            if mp:
+                name = f"sa_k_systolic_pk<{METH[mp.group(1)]},K{mp.group(2)}>"
+            elif m:
+                name = f"sa_k_systolic<{METH[m.group(1)]},G{m.group(2)},K{m.group(3)}>" + (" strips" if m.group(4) == "true" else "")
+            else:
                 continue
-            name = f"sa_k_systolic<{METH[m.group(1)]},G{m.group(2)},K{m.group(3)}>" + (" strips" if m.group(4) == "true" else "")
             acc[name] += float(r["Counter_Value"])
             n[name].add(r["Dispatch_Id"])
     return acc, {k: len(v) for k, v in n.items()}
@@ -36,7 +40,7 @@ for k in sorted(fetch):
                    "half of coalesced read bytes; the byte-granular loads here are uncalibrated, so this is an upper "
                    "estimate), WRITE_SIZE as is",
            "traffic_bytes_per_launch": (2 * f_kb + w_kb) * 1024}
-    tag = re.sub(r"[^A-Za-z0-9]+", "_", k.split("<")[1]).strip("_")
+    tag = ("pk_" if "_pk<" in k else "") + re.sub(r"[^A-Za-z0-9]+", "_", k.split("<")[1]).strip("_")
     path = os.path.join("profiles", f"{run}_{tag}_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(path, out["traffic_bytes_per_launch"])

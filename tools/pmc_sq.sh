@@ -17,7 +17,7 @@ for f in glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recur
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "systolic" not in k: continue
-        k = k.split("sa_k_systolic")[1][:14]
+        k = k.split("sa_k_systolic")[1][:16]
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
 for k in sorted(acc):
     print(k)
