@@ -215,11 +215,13 @@ def test_baseline_full_size_cfg4_cfg5(cfg_name, sa, oracle, torch_cuda):
     method allows (a property no sample needs)."""
     torch = torch_cuda
     seqs, cfg = make_config(cfg_name)
-    if cfg_name == "cfg5":  # `-f 0.9`: planted near-duplicates are dropped before alignment (host filter of the CLI)
+    if cfg_name == "cfg5":  # `-f 0.9`: planted near-duplicates are dropped before alignment -- sa_hip_filter at full size
         from tests.host_binding import Host
         amino = sa.Scoring.from_names("nw", "blosum62", gap_pen=4).lut
-        kept = Host().filter(seqs, amino, 0.9)
+        keep = sa.hip_filter(sa.SequenceStore.from_sequences(seqs), 0.9)  # relation on the device, 100 000 sequences
+        kept = [s for s, k in zip(seqs, keep) if k]
         assert 0.85 * len(seqs) < len(kept) < 0.95 * len(seqs)
+        assert kept == Host().filter(seqs, amino, 0.9)                    # == the exact blocked CPU implementation
         assert oracle.filter(sa.SequenceStore.from_sequences(kept[:3000]), 0.9).all()  # survivors are mutually dissimilar
         seqs = kept
     store = sa.SequenceStore.from_sequences(seqs)
