@@ -69,6 +69,7 @@ struct sa_ctx {
 	struct Plan {
 		int64_t start = -1, count = -1;
 		int32_t chunk = SA_SYS_CHUNK; /* sequences per group stream chosen for this range */
+		int32_t chunk_pk = SA_SYS_CHUNK; /* ... for the packed classes (their tiles are workgroup-tiles of two columns) */
 		std::vector<ClassLaunch> classes;
 		std::vector<std::pair<int64_t, int64_t>> generic; /* (start, count) runs for the generic kernels */
 		uint64_t stamp = 0;
@@ -667,6 +668,16 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		if (ctx->env_chunk)
 			chunk = ctx->env_chunk;
 		plan.chunk = chunk;
+		/* packed classes: a workgroup-tile covers 2 columns x SA_PK_WPB * 8 streams of `chunk` sequences and ~4
+		 * workgroups are resident per CU: keep >= 8 tiles per resident workgroup so that a small range (one rank's
+		 * share at 8 GPUs, a super-chunk) still drains evenly */
+		const int64_t want_pk = (int64_t)ctx->persistent_wgs; /* = 32 x CUs = 8 x (4 workgroups per CU) */
+		int32_t cpk = SA_SYS_CHUNK;
+		while (cpk > 4 && count / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < want_pk)
+			cpk >>= 1;
+		if (ctx->env_chunk)
+			cpk = ctx->env_chunk;
+		plan.chunk_pk = cpk;
 	}
 	const int32_t j0 = column_of(start), j1 = column_of(end - 1);
 	for (int32_t j = j0; j <= j1; j++) {
@@ -712,7 +723,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		const auto &rw = rows_of[(size_t)cls];
 		if (rw.empty())
 			continue;
-		const int64_t rows = (int64_t)SA_PK_WPB * 8 * plan.chunk;
+		const int64_t rows = (int64_t)SA_PK_WPB * 8 * plan.chunk_pk;
 		tp[(size_t)cls].push_back(0);
 		for (size_t c = 0; c < rw.size(); c += 2) {
 			const auto &a = rw[c], &b = rw[c + 1 < rw.size() ? c + 1 : c];
@@ -893,7 +904,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.pk_floor = ctx->pk_floor;
 		}
 		a.counter = counters + cl.cls;
-		a.chunk = is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
+		a.chunk = is_pk ? ctx->plan->chunk_pk : is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
 		if (is_long) {
 			/* scratch: two lines (V and X) of a wave's longest possible row stream, for every wave of as many
 			 * workgroups as fit a 4 GiB budget */
