@@ -929,8 +929,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
 		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
 		unsigned long long *d_stamps = nullptr;
-		if (ctx->env_stamps && !is_pk) {
+		if (ctx->env_stamps) {
 			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
+			SA_HIP_CHECK(hipMemset(d_stamps, 0, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
 			a.stamps = d_stamps;
 		}
 		hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -948,6 +949,17 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			SA_HIP_CHECK(hipStreamSynchronize(s), return 1);
 			SA_HIP_CHECK(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost), return 1);
 			(void)hipFree(d_stamps);
+			if (is_pk) { /* packed kernels: totals in the first triple: wave-steps executed, stream rows (8 per wave-step at best), wave-tiles */
+				fprintf(stderr, "[stamps] %s: %llu wave-tiles, %.0f steps per wave-tile, %.3f executed step slots per stream row (1.0 = no bubbles)\n",
+					name, h[2], (double)h[0] / (double)h[2], (double)h[0] * 8.0 / (double)h[1]);
+				if (!timed_end(name, e0, e1, cl.pairs, cl.cells))
+					return 1;
+				if (fan_out) {
+					SA_HIP_CHECK(hipEventRecord(ctx->join_ev[side_k], s), return 1);
+					SA_HIP_CHECK(hipStreamWaitEvent(caller, ctx->join_ev[side_k], 0), return 1);
+				}
+				continue;
+			}
 			double cyc = 0, rt = 0, steps = 0;
 			for (int32_t k = 0; k < cl.ntiles; k++) {
 				cyc += (double)h[3 * (size_t)k];
