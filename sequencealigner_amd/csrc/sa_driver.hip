@@ -56,7 +56,7 @@ struct sa_ctx {
 	int32_t sys_pconst = 0, sys_q = 0;
 	int64_t sys_gain = 0, sys_slack = 0;
 	/* packed-u16 kernels (sa_systolic_pk.inc): column classes K = 1..pk_kmax run there (0: none), see pk_setup */
-	int pk_kmax = 0;
+	int pk_kmax = 0, pk16_kmax = 0; /* 8-lane groups: K = 1..pk_kmax; 16-lane groups: K = SA_PK_K16_MIN..pk16_kmax */
 	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0;
 	int64_t pk_gain = 0, pk_slack = 0, pk_extra = 0;
 	/* launch plans of recently used packed ranges (callers loop over the same few ranges) */
@@ -299,14 +299,14 @@ static int systolic_class_for(int32_t n)
 /* frame shifts a value of the packed kernels can see before its last use: its own terminator entering the group plus
  * one per later terminator entering while its last rows travel through the remaining G - 1 = 7 lanes (terminators are
  * at least two stream positions apart) */
-constexpr int PK_LIVE = 4;
+static int pk_live(int g) { return 1 + (g - 1) / 2; } /* 4 for 8-lane groups, 8 for 16-lane groups */
 
-static int32_t pk_delta(const sa_ctx *ctx, int k) { return (int32_t)(ctx->pk_gain * 8 * k + ctx->pk_slack); }
-static int32_t pk_base(const sa_ctx *ctx, int k)
+static int32_t pk_delta(const sa_ctx *ctx, int g, int k) { return (int32_t)(ctx->pk_gain * g * k + ctx->pk_slack); }
+static int32_t pk_base(const sa_ctx *ctx, int g, int k)
 {
-	/* (Gotoh: values reach BASE + 3q; SW: the lanes start up to 8 |e| below the baseline) */
-	return PK_LIVE * pk_delta(ctx, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4 +
-	       (ctx->sc.method == SA_METHOD_SW ? 8 * std::abs(ctx->sc.gap_ext) : 0);
+	/* (Gotoh: values reach BASE + 3q; SW: the lanes start up to G |e| below the baseline) */
+	return pk_live(g) * pk_delta(ctx, g, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4 +
+	       (ctx->sc.method == SA_METHOD_SW ? g * std::abs(ctx->sc.gap_ext) : 0);
 }
 
 /* Decides which column classes the packed-u16 kernels reproduce exactly (see sa_systolic_pk.inc): profile entries
@@ -315,7 +315,7 @@ static int32_t pk_base(const sa_ctx *ctx, int k)
 static void pk_setup(sa_ctx *ctx)
 {
 	const sa_scoring &sc = ctx->sc;
-	ctx->pk_kmax = 0;
+	ctx->pk_kmax = ctx->pk16_kmax = 0;
 	if (!ctx->sys_ok || getenv("SA_HIP_NO_PK"))
 		return;
 	int64_t smax = INT32_MIN, smin = INT32_MAX;
@@ -336,7 +336,7 @@ static void pk_setup(sa_ctx *ctx)
 		slack = -o - e + 2;
 		floor_v = -o - 2 * e + 2;
 		q = o + e; /* (only its magnitude is used below: margins) */
-		extra = (int64_t)SA_SYS_CHUNK * ((int64_t)ctx->max_len + 1) * (-e) + 8 * (-e);
+		extra = (int64_t)SA_SYS_CHUNK * ((int64_t)ctx->max_len + 1) * (-e) + 16 * (-e);
 	} else if (sc.method == SA_METHOD_NW) {
 		pconst = -2 * g;
 		pmax = smax + pconst;
@@ -361,13 +361,18 @@ static void pk_setup(sa_ctx *ctx)
 	ctx->pk_gain = gain;
 	ctx->pk_slack = slack;
 	ctx->pk_floor = (int32_t)floor_v;
+	const int64_t fixed = floor_v + 4 * (-q) + 4 + pmax + (-q) + extra;
 	for (int k = 1; k <= SA_PK_KMAX; k++) {
-		const int64_t delta = gain * 8 * k + slack;
-		const int64_t top = (PK_LIVE + 1) * delta + floor_v + 4 * (-q) + 4 + pmax + (-q) + extra;
-		if (top > 65535)
+		if ((pk_live(8) + 1) * (gain * 8 * k + slack) + fixed > 65535)
 			break;
 		ctx->pk_kmax = k;
 	}
+	if (ctx->pk_kmax == SA_PK_KMAX && !getenv("SA_HIP_NO_PK16")) /* wider columns: 16-lane groups, twice as many shifts in flight */
+		for (int k = SA_PK_K16_MIN; k <= SA_PK_KMAX; k++) {
+			if ((pk_live(16) + 1) * (gain * 16 * k + slack) + fixed > 65535)
+				break;
+			ctx->pk16_kmax = k;
+		}
 }
 
 extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa_scoring *sc)
@@ -686,8 +691,11 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		if (ib <= ia)
 			continue;
 		const int32_t n = ctx->meta[(size_t)j].len;
-		if ((n + 7) / 8 <= ctx->pk_kmax) { /* packed-u16 class K = ceil(n / 8): tiles are counted per column PAIR below */
-			const size_t pc = (size_t)(SA_PK_CLASS0 + (n + 7) / 8);
+		const int k8 = (n + 7) / 8, k16 = (n + 15) / 16;
+		if (k8 <= ctx->pk_kmax || (k16 >= SA_PK_K16_MIN && k16 <= ctx->pk16_kmax)) {
+			/* packed-u16 class K = ceil(n / 8) (8-lane groups) or ceil(n / 16) (16-lane groups): tiles are counted per
+			 * column PAIR below */
+			const size_t pc = (size_t)(k8 <= ctx->pk_kmax ? SA_PK_CLASS0 + k8 : SA_PK16_CLASS0 + k16);
 			jl[pc].push_back(j);
 			rows_of[pc].emplace_back((int32_t)ia, (int32_t)ib);
 			cpairs[pc] += ib - ia;
@@ -723,7 +731,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		const auto &rw = rows_of[(size_t)cls];
 		if (rw.empty())
 			continue;
-		const int64_t rows = (int64_t)SA_PK_WPB * 8 * plan.chunk_pk;
+		const int64_t rows = (int64_t)SA_PK_WPB * (cls >= SA_PK16_CLASS0 ? 4 : 8) * plan.chunk_pk;
 		tp[(size_t)cls].push_back(0);
 		for (size_t c = 0; c < rw.size(); c += 2) {
 			const auto &a = rw[c], &b = rw[c + 1 < rw.size() ? c + 1 : c];
@@ -874,9 +882,10 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			SA_HIP_CHECK(hipStreamWaitEvent(s, ctx->fork_ev, 0), return 1);
 		}
 		const bool is_pk = cl.cls >= SA_PK_CLASS0;
-		const int pk_k = cl.cls - SA_PK_CLASS0;
+		const int pk_g = cl.cls >= SA_PK16_CLASS0 ? 16 : 8;
+		const int pk_k = cl.cls - (pk_g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
 		const bool is_long = cl.cls == SA_SYS_CLASS_LONG;
-		const int64_t W = is_pk ? 8 * pk_k : is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
+		const int64_t W = is_pk ? pk_g * pk_k : is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
 					  : SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
 		SaSysArgs a{};
 		a.codes = ctx->d_codes;
@@ -899,8 +908,8 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		if (is_pk) {
 			a.pconst = ctx->pk_pconst;
 			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
-			a.delta = pk_delta(ctx, pk_k);
-			a.pk_base = pk_base(ctx, pk_k);
+			a.delta = pk_delta(ctx, pk_g, pk_k);
+			a.pk_base = pk_base(ctx, pk_g, pk_k);
 			a.pk_floor = ctx->pk_floor;
 		}
 		a.counter = counters + cl.cls;
@@ -920,7 +929,8 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		}
 		char name[64];
 		if (is_pk)
-			snprintf(name, sizeof(name), "sa_k_systolic_pk<%s,K%d>", METHOD_TAG[ctx->sc.method], pk_k);
+			snprintf(name, sizeof(name), pk_g == 16 ? "sa_k_systolic_pk16<%s,K%d>" : "sa_k_systolic_pk<%s,K%d>",
+				 METHOD_TAG[ctx->sc.method], pk_k);
 		else if (is_long)
 			snprintf(name, sizeof(name), "sa_k_systolic<%s,G64,K16,strips>", METHOD_TAG[ctx->sc.method]);
 		else
@@ -940,7 +950,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		const int wgs = (int)std::min<int64_t>(is_pk ? ctx->persistent_wgs / 4 : is_long ? ctx->long_wgs : ctx->persistent_wgs,
 						       cl.ntiles);
 		if (is_pk) {
-			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pk_k, a, wgs, s), return 1);
+			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pk_g, pk_k, a, wgs, s), return 1);
 		} else {
 			SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
 		}

@@ -83,8 +83,14 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 #define SA_PK_K_LIST(X) \
 	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
 	X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
-/* class index space of a plan: [0, SA_SYS_NCLASSES) s32 classes, SA_SYS_CLASS_LONG, then SA_PK_CLASS0 + K */
-enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PLAN_NCLASSES = SA_PK_CLASS0 + SA_PK_KMAX + 1 };
+/* ... and 16-lane groups with K = 13..24 columns per lane for 193..384 columns (one group per DPP row: the 16 lanes of a
+ * ds_read_b128 phase are 16 distinct slots, so one profile copy is conflict-free) */
+#define SA_PK_K16_MIN 13
+#define SA_PK_K16_LIST(X) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+/* class index space of a plan: [0, SA_SYS_NCLASSES) s32 classes, SA_SYS_CLASS_LONG, then SA_PK_CLASS0 + K (8-lane groups),
+ * then SA_PK16_CLASS0 + K (16-lane groups) */
+enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 + SA_PK_KMAX + 1,
+	     SA_PLAN_NCLASSES = SA_PK16_CLASS0 + SA_PK_KMAX + 1 };
 
 struct SaSysArgs {
 	const uint8_t *codes;    /* encoded store, tight layout: sequence k at off[k], terminator after it */
@@ -113,7 +119,7 @@ struct SaSysArgs {
 /* `workgroups` persistent workgroups pull the launch's wave-tiles from a.counter */
 hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workgroups, hipStream_t s);
 /* packed-u16 kernels: class K of SA_PK_K_LIST; jlist holds the columns, tprefix the tiles before each column PAIR */
-hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int workgroups, hipStream_t s);
+hipError_t sa_launch_systolic_pk(int method, int g, int k, const SaSysArgs &a, int workgroups, hipStream_t s);
 /* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */
 hipError_t sa_warm_kernels(int method);
 

@@ -19,19 +19,19 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 	}
 }
 
-hipError_t sa_launch_systolic_pk_nw(int k, const SaSysArgs &a, int tiles, hipStream_t s);
-hipError_t sa_launch_systolic_pk_ga(int k, const SaSysArgs &a, int tiles, hipStream_t s);
-hipError_t sa_launch_systolic_pk_sw(int k, const SaSysArgs &a, int tiles, hipStream_t s);
+hipError_t sa_launch_systolic_pk_nw(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);
+hipError_t sa_launch_systolic_pk_ga(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);
+hipError_t sa_launch_systolic_pk_sw(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);
 
-hipError_t sa_launch_systolic_pk(int method, int k, const SaSysArgs &a, int tiles, hipStream_t s)
+hipError_t sa_launch_systolic_pk(int method, int g, int k, const SaSysArgs &a, int tiles, hipStream_t s)
 {
 	switch (method) {
 	case SA_METHOD_NW:
-		return sa_launch_systolic_pk_nw(k, a, tiles, s);
+		return sa_launch_systolic_pk_nw(g, k, a, tiles, s);
 	case SA_METHOD_GA:
-		return sa_launch_systolic_pk_ga(k, a, tiles, s);
+		return sa_launch_systolic_pk_ga(g, k, a, tiles, s);
 	case SA_METHOD_SW:
-		return sa_launch_systolic_pk_sw(k, a, tiles, s);
+		return sa_launch_systolic_pk_sw(g, k, a, tiles, s);
 	default:
 		return hipErrorInvalidValue;
 	}

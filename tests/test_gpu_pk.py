@@ -24,7 +24,10 @@ def test_class_boundaries_and_padding(method, gaps, sa, oracle):
     lens = []
     for k in range(1, 25):
         lens += [8 * k - 1, 8 * k, 8 * k + 1] if k < 24 else [8 * k - 1, 8 * k]
-    lens += [1, 2, 3, 5, 193, 200]  # below the first class, above the last packed class (s32 kernels)
+    lens += [1, 2, 3, 5, 193, 200]  # below the first class; the first 16-lane class
+    for k in range(13, 25):           # 16-lane groups: W = 16 K = 208 .. 384 (the last ones fall to the s32 kernels when
+        lens += [16 * k - 1, 16 * k, 16 * k + 1]  # their DELTA does not fit u16: NW blosum62 gap 4 at K = 24)
+    lens += [400, 513]
     seqs = [seq_of(n, 1000 + i) for i, n in enumerate(lens)]
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
@@ -35,7 +38,8 @@ def test_class_boundaries_and_padding(method, gaps, sa, oracle):
 def test_streams_of_very_short_rows(method, gaps, sa, oracle):
     """hundreds of rows of length 1..3 in front of long columns: a terminator every other stream position, i.e. the
     maximum number of frame shifts between a value's birth and its capture"""
-    seqs = [seq_of(1 + (i % 3), 50 + i) for i in range(700)] + [seq_of(n, 9000 + n) for n in (64, 100, 101, 127, 128, 150, 191, 192)]
+    seqs = [seq_of(1 + (i % 3), 50 + i) for i in range(700)] + [seq_of(n, 9000 + n) for n in (64, 100, 101, 127, 128, 150, 191, 192,
+                                                                                              200, 256, 300, 352, 384)]
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
     assert np.array_equal(sa.hip_align(store, scoring, triangular=True), oracle.align(store, scoring, triangular=True, threads=8))
@@ -45,7 +49,7 @@ def test_ranges_that_cut_column_pairs(sa, oracle):
     """sa_ctx_align_range on ranges that start / end inside a column, so that the two columns of a packed tile have
     different row ranges (or only one of them belongs to the range)"""
     import torch
-    seqs = make_protein_set(260, 90, 104, 17)  # two or three classes, many pairs per class
+    seqs = make_protein_set(200, 90, 104, 17) + make_protein_set(60, 250, 270, 18)  # few classes, many pairs per class
     store = sa.SequenceStore.from_sequences(seqs)
     rng = np.random.default_rng(5)
     for method, gaps in METHODS:
@@ -70,7 +74,7 @@ def test_ranges_that_cut_column_pairs(sa, oracle):
     ("sw", "blosum62", dict(gap_open=2, gap_extend=5)),      # |open| < |extend|: not the packed formulation
 ])
 def test_scorings_that_partly_fit_u16(method, matrix, gaps, sa, oracle):
-    seqs = make_protein_set(150, 1, 190, 23)
+    seqs = make_protein_set(150, 1, 390, 23)
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(method, matrix, **gaps)
     assert np.array_equal(sa.hip_align(store, scoring, triangular=True), oracle.align(store, scoring, triangular=True))
@@ -78,7 +82,7 @@ def test_scorings_that_partly_fit_u16(method, matrix, gaps, sa, oracle):
 
 def test_packed_and_s32_kernel_families_agree(sa, monkeypatch):
     """SA_HIP_NO_PK routes the same job to the s32 kernels: two independent implementations, one result"""
-    sets = [make_protein_set(500, 60, 180, 31), make_dna_set(400, 100, 190, 32, iupac=True)]
+    sets = [make_protein_set(500, 60, 380, 31), make_dna_set(400, 100, 390, 32, iupac=True)]
     for seqs, matrix in zip(sets, ("blosum62", "nuc44")):
         store = sa.SequenceStore.from_sequences(seqs)
         for method, gaps in METHODS:

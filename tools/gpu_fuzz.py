@@ -28,7 +28,7 @@ while time.time() - t0 < budget:
     if regime == 0:
         lens = rng.integers(1, 10, n)
     elif regime == 1:
-        lens = rng.integers(40, 200, n)
+        lens = rng.integers(40, 400, n)
     elif regime == 2:
         lens = rng.integers(1, 600, min(n, 120))
     elif regime == 3:

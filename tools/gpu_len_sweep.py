@@ -8,7 +8,7 @@ from tests.oracle_binding import Oracle
 from tests.synth import make_protein_set
 
 o = Oracle()
-regimes = [(300, 500, 3000), (150, 250, 5000), (600, 1000, 1500)]
+regimes = [(int(a), int(b), int(c)) for a, b, c in zip(sys.argv[1::3], sys.argv[2::3], sys.argv[3::3])] or [(300, 500, 3000), (150, 250, 5000), (600, 1000, 1500)]
 for lo, hi, n in regimes:
     seqs = make_protein_set(n, lo, hi, 11)
     store = sa.SequenceStore.from_sequences(seqs)
