@@ -135,7 +135,7 @@ def cpu_baseline(seqs, cfg, target_s: float) -> dict:
     }
 
 
-def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_size: bool) -> dict:
+def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_size: bool = True) -> dict:
     """dominant kernel: algorithmic HBM bytes of ONE launch (4 B per pair written + the sequence store
     and its offsets read once) / that kernel's average launch duration (HIP events on the launch stream)"""
     launches = max(tm["launches"], 1)
@@ -148,7 +148,8 @@ def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_siz
     traffic = None
     for tf in sorted((ROOT / "profiles").glob("*_traffic.json")):
         tj = json.loads(tf.read_text())
-        if (tj.get("kernel") == tm["kernel"] and tj.get("workload") == workload and world == 1 and full_size
+        if (tj.get("kernel") == tm["kernel"] and tj.get("workload") == workload and world == 1
+                and (tj["n_sequences"] == store.num if "n_sequences" in tj else full_size)
                 and abs(tj.get("pairs_per_launch", k_pairs) - k_pairs) <= 0.02 * k_pairs):
             traffic = tj["traffic_bytes_per_launch"]
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
