@@ -6,7 +6,8 @@ mi = {"nw": 0, "ga": 1, "sw": 2}[m]
 src = f"/root/repo/sequencealigner_amd/csrc/sa_systolic_pk_{m}.hip"
 asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-x", "hip", "--cuda-device-only",
                       "-S", src, "-o", "-"], capture_output=True, text=True).stdout
-name = f"_ZN12_GLOBAL__N_116sa_k_systolic_pkILi{mi}ELi{k}EEEv9SaSysArgs"
+g = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+name = f"_ZN12_GLOBAL__N_116sa_k_systolic_pkILi{mi}ELi{g}ELi{k}EEEv9SaSysArgs"
 body = asm[asm.index(name + ":"):]
 body = body[:body.index("s_endpgm")]
 L = body.split("\n")
