@@ -57,7 +57,7 @@ struct sa_ctx {
 	int64_t sys_gain = 0, sys_slack = 0;
 	/* packed-u16 kernels (sa_systolic_pk.inc): column classes K = 1..pk_kmax run there (0: none), see pk_setup */
 	int pk_kmax = 0, pk16_kmax = 0; /* 8-lane groups: K = 1..pk_kmax; 16-lane groups: K = SA_PK_K16_MIN..pk16_kmax */
-	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0;
+	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0; /* pk_floor: margin below the lowest legitimate value (part of BASE) */
 	int64_t pk_gain = 0, pk_slack = 0, pk_extra = 0;
 	/* launch plans of recently used packed ranges (callers loop over the same few ranges) */
 	struct ClassLaunch {
@@ -910,7 +910,6 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
 			a.delta = pk_delta(ctx, pk_g, pk_k);
 			a.pk_base = pk_base(ctx, pk_g, pk_k);
-			a.pk_floor = ctx->pk_floor;
 		}
 		a.counter = counters + cl.cls;
 		a.chunk = is_pk ? ctx->plan->chunk_pk : is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;

@@ -109,8 +109,7 @@ struct SaSysArgs {
 	int32_t chunk;           /* sequences per group stream of a wave-tile, 1..SA_SYS_CHUNK            */
 	int32_t *long_scratch;   /* strip-mined launch: per wave 2 lines of long_stride/2 ints            */
 	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
-	int32_t pk_base;         /* packed kernels: the constant baseline BASE and the lowest value a register may hold */
-	int32_t pk_floor;
+	int32_t pk_base;         /* packed kernels: the constant baseline BASE                                     */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */

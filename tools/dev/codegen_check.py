@@ -1,5 +1,5 @@
 """development: per-step instruction mix of a packed kernel's main loop (catches register-copy blow-ups)
-usage: codegen_check.py <method nw|ga|sw> <K>"""
+usage: codegen_check.py <method nw|ga|sw> <K> [G = 8|16]"""
 import re, subprocess, sys, collections
 m, k = sys.argv[1], int(sys.argv[2])
 mi = {"nw": 0, "ga": 1, "sw": 2}[m]
