@@ -28,6 +28,7 @@ struct sa_ctx {
 	sa_scoring sc{};
 	std::vector<sa_meta> meta;     /* device-side (tight) layout: off[k] = sum_{i<k}(len_i+1)          */
 	std::vector<int32_t> off;      /* num+1 tight offsets                                                */
+	std::vector<uint8_t> codes;    /* host copy of the encoded store (arranged copies are made from it)  */
 	uint8_t *d_codes = nullptr;
 	sa_meta *d_meta = nullptr;
 	int32_t *d_off = nullptr;
@@ -59,6 +60,16 @@ struct sa_ctx {
 	int pk_kmax = 0, pk16_kmax = 0; /* 8-lane groups: K = 1..pk_kmax; 16-lane groups: K = SA_PK_K16_MIN..pk16_kmax */
 	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0; /* pk_floor: margin below the lowest legitimate value (part of BASE) */
 	int64_t pk_gain = 0, pk_slack = 0, pk_extra = 0;
+	/* arranged copies of the store for the packed kernels' row streams (arranged_store), one per tile shape */
+	struct Arranged {
+		int ng = 0, ch = 0;      /* streams per wave, sequences per stream */
+		int32_t block = 0;       /* rows per arranged block                 */
+		uint8_t *d_codes = nullptr;
+		int32_t *d_off = nullptr, *d_rowmap = nullptr, *d_posmap = nullptr;
+	};
+	std::vector<Arranged> arranged;
+	bool env_no_sort = false;
+	bool out_is_host = false; /* the range being launched stores straight into host memory (sa_ctx_align_host) */
 	/* launch plans of recently used packed ranges (callers loop over the same few ranges) */
 	struct ClassLaunch {
 		int cls = 0;
@@ -399,11 +410,13 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	for (int32_t k = 0; k < in.num; k++)
 		ctx->meta[(size_t)k] = sa_meta{ off[(size_t)k], in.meta[k].len };
 	ctx->off = off;
+	ctx->codes = codes;
 	ctx->env_serial_classes = getenv("SA_HIP_SERIAL_CLASSES") != nullptr;
 	ctx->env_stamps = getenv("SA_HIP_STAMPS") != nullptr;
 	ctx->env_no_pin = getenv("SA_HIP_NO_PIN") != nullptr;
 	ctx->env_no_shells = getenv("SA_HIP_NO_SHELLS") != nullptr;
 	ctx->env_no_direct = getenv("SA_HIP_NO_DIRECT") != nullptr;
+	ctx->env_no_sort = getenv("SA_HIP_NO_SORT") != nullptr;
 	if (const char *e = getenv("SA_HIP_CHUNK")) /* development switch: fixed stream length */
 		ctx->env_chunk = std::max(1, std::min(SA_SYS_CHUNK, atoi(e)));
 	systolic_setup(ctx);
@@ -469,6 +482,12 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 	}
 	plan_release(ctx);
 	deliver_release(ctx);
+	for (auto &ar : ctx->arranged) {
+		(void)hipFree(ar.d_codes);
+		(void)hipFree(ar.d_off);
+		(void)hipFree(ar.d_rowmap);
+		(void)hipFree(ar.d_posmap);
+	}
 	(void)hipFree(ctx->d_codes);
 	(void)hipFree(ctx->d_meta);
 	(void)hipFree(ctx->d_off);
@@ -492,6 +511,99 @@ extern "C" void sa_ctx_destroy(sa_ctx *ctx)
 }
 
 extern "C" int64_t sa_ctx_pairs(const sa_ctx *ctx) { return ctx ? ctx->pairs : -1; }
+
+/* Arranged copy of the store for the row streams of the packed kernels (sa_systolic_pk.inc).
+ *
+ * A workgroup-tile streams SA_PK_WPB waves x ng streams x ch sequences.  What a terminator costs a wave is the event
+ * step it causes (the frame shift of every register, the capture of a score pair), and the step is shared by all
+ * streams of the wave whose terminators pass at the same stream position; streams of different lengths also leave
+ * bubbles at the end of a tile.  So the rows of the matrix are cut into aligned blocks of `block` sequences (a multiple
+ * of the tile's rows) and every block is re-ordered for this tile shape:
+ *   - sequences of equal length are taken ng at a time: a PURE round, one sequence for each stream of a wave;
+ *   - what is left over (< ng per length) is sorted by length and cut into MIXED rounds of ng neighbours;
+ *   - the rounds, longest first and the mixed ones last, are dealt over the block's wave slots boustrophedon, one per
+ *     slot and pass: every wave gets ch rounds of nearly the same total length, its pure rounds first.
+ * As long as a wave is in its pure rounds all its streams are in step.  Rows past the last full block keep their order.
+ * The copy is (codes, off) in position order plus rowmap (position -> row) and posmap (row -> position). */
+static bool arranged_store(sa_ctx *ctx, int ng, int ch, int32_t block, const sa_ctx::Arranged **out)
+{
+	*out = nullptr;
+	for (const auto &ar : ctx->arranged)
+		if (ar.ng == ng && ar.ch == ch && ar.block == block) {
+			*out = &ar;
+			return true;
+		}
+	const int32_t num = ctx->num;
+	const int32_t wave_rows = ng * ch;
+	if (block <= 0 || block % (wave_rows * SA_PK_WPB) != 0 || block > num)
+		return true; /* no full block: nothing to arrange */
+	std::vector<int32_t> rowmap((size_t)num), posmap((size_t)num), off_s((size_t)num + 1);
+	for (int32_t i = 0; i < num; i++)
+		rowmap[(size_t)i] = i;
+	const int32_t slots = block / wave_rows;
+	std::vector<int32_t> idx((size_t)block), rounds, rest;
+	for (int32_t b0 = 0; b0 + block <= num; b0 += block) {
+		for (int32_t k = 0; k < block; k++)
+			idx[(size_t)k] = b0 + k;
+		std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return ctx->meta[(size_t)a].len > ctx->meta[(size_t)b].len; });
+		rounds.clear();
+		rest.clear();
+		for (int32_t k = 0; k < block;) {
+			int32_t e = k;
+			while (e < block && ctx->meta[(size_t)idx[(size_t)e]].len == ctx->meta[(size_t)idx[(size_t)k]].len)
+				e++;
+			const int32_t pure = (e - k) / ng * ng;
+			rounds.insert(rounds.end(), idx.begin() + k, idx.begin() + k + pure);
+			rest.insert(rest.end(), idx.begin() + k + pure, idx.begin() + e);
+			k = e;
+		}
+		rounds.insert(rounds.end(), rest.begin(), rest.end()); /* (block and the pure part are multiples of ng) */
+		for (int32_t r = 0; r < block / ng; r++) {
+			const int32_t pass = r / slots, w = r % slots;
+			const int32_t slot = (pass & 1) ? slots - 1 - w : w;
+			for (int g = 0; g < ng; g++) {
+				/* mixed rounds alternate their direction, so that the streams of a wave even out */
+				const int gg = (pass & 1) ? ng - 1 - g : g;
+				rowmap[(size_t)(b0 + slot * wave_rows + gg * ch + pass)] = rounds[(size_t)(r * ng + g)];
+			}
+		}
+	}
+	std::vector<uint8_t> codes_s(ctx->codes.size());
+	off_s[0] = 0;
+	for (int32_t p = 0; p < num; p++) {
+		const int32_t i = rowmap[(size_t)p];
+		posmap[(size_t)i] = p;
+		const int32_t n = ctx->off[(size_t)i + 1] - ctx->off[(size_t)i];
+		memcpy(codes_s.data() + off_s[(size_t)p], ctx->codes.data() + ctx->off[(size_t)i], (size_t)n);
+		off_s[(size_t)p + 1] = off_s[(size_t)p] + n;
+	}
+	sa_ctx::Arranged ar;
+	ar.ng = ng;
+	ar.ch = ch;
+	ar.block = block;
+	bool ok = false;
+	do {
+		SA_HIP_CHECK(hipMalloc(&ar.d_codes, codes_s.size()), break);
+		SA_HIP_CHECK(hipMalloc(&ar.d_off, sizeof(int32_t) * off_s.size()), break);
+		SA_HIP_CHECK(hipMalloc(&ar.d_rowmap, sizeof(int32_t) * rowmap.size()), break);
+		SA_HIP_CHECK(hipMalloc(&ar.d_posmap, sizeof(int32_t) * posmap.size()), break);
+		SA_HIP_CHECK(hipMemcpy(ar.d_codes, codes_s.data(), codes_s.size(), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(ar.d_off, off_s.data(), sizeof(int32_t) * off_s.size(), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(ar.d_rowmap, rowmap.data(), sizeof(int32_t) * rowmap.size(), hipMemcpyHostToDevice), break);
+		SA_HIP_CHECK(hipMemcpy(ar.d_posmap, posmap.data(), sizeof(int32_t) * posmap.size(), hipMemcpyHostToDevice), break);
+		ok = true;
+	} while (0);
+	if (!ok) {
+		(void)hipFree(ar.d_codes);
+		(void)hipFree(ar.d_off);
+		(void)hipFree(ar.d_rowmap);
+		(void)hipFree(ar.d_posmap);
+		return false;
+	}
+	ctx->arranged.push_back(ar);
+	*out = &ctx->arranged.back();
+	return true;
+}
 
 /* j of packed index p: largest j with j(j-1)/2 <= p */
 static int32_t column_of(int64_t p)
@@ -910,6 +1022,25 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
 			a.delta = pk_delta(ctx, pk_g, pk_k);
 			a.pk_base = pk_base(ctx, pk_g, pk_k);
+			if (!ctx->env_no_sort) {
+				/* Arranged row streams.  Scores stored straight into host memory must leave in row order: there a block
+				 * is one tile; in device memory a block may span several tiles (their stores scatter inside it). */
+				const int ng = 64 / pk_g;
+				const int32_t rows = SA_PK_WPB * ng * ctx->plan->chunk_pk;
+				int32_t block = rows;
+				if (!ctx->out_is_host && rows < SA_PK_SORT_ROWS && SA_PK_SORT_ROWS % rows == 0)
+					block = SA_PK_SORT_ROWS;
+				const sa_ctx::Arranged *ar = nullptr;
+				if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))
+					return 1;
+				if (ar) {
+					a.codes_s = ar->d_codes;
+					a.off_s = ar->d_off;
+					a.rowmap = ar->d_rowmap;
+					a.posmap = ar->d_posmap;
+					a.sort_rows = ar->block;
+				}
+			}
 		}
 		a.counter = counters + cl.cls;
 		a.chunk = is_pk ? ctx->plan->chunk_pk : is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
@@ -1448,7 +1579,9 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 	bool ok;
 	if (direct) {
 		const auto t_phase = std::chrono::steady_clock::now();
+		ctx->out_is_host = true;
 		ok = sa_ctx_align_range(ctx, start, total, direct, d.compute) == 0;
+		ctx->out_is_host = false;
 		if (ok) {
 			SA_HIP_CHECK(hipStreamSynchronize(d.compute), ok = false);
 		}

@@ -79,6 +79,7 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 /* packed-u16 kernels (sa_systolic_pk.inc): 8-lane groups, K = 1..SA_PK_KMAX columns per lane (W = 8 K <= 192), two
  * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
 #define SA_PK_WPB 4
+#define SA_PK_SORT_ROWS 2048 /* rows per arranged block of the row store when a tile is smaller (sa_driver.hip: arranged_store) */
 #define SA_PK_KMAX 24
 #define SA_PK_K_LIST(X) \
 	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
@@ -110,6 +111,12 @@ struct SaSysArgs {
 	int32_t *long_scratch;   /* strip-mined launch: per wave 2 lines of long_stride/2 ints            */
 	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
 	int32_t pk_base;         /* packed kernels: the constant baseline BASE                                     */
+	/* packed kernels: arranged copy of the store in blocks of sort_rows sequences (0: none), see arranged_store */
+	const uint8_t *codes_s;
+	const int32_t *off_s;    /* num+1 offsets into codes_s by position                                          */
+	const int32_t *rowmap;   /* position -> row                                                                 */
+	const int32_t *posmap;   /* row -> position                                                                 */
+	int32_t sort_rows;
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
