@@ -74,6 +74,7 @@ struct sa_ctx {
 	struct ClassLaunch {
 		int cls = 0;
 		int32_t ncols = 0, ntiles = 0;
+		int32_t npart = 0; /* packed classes: partial tiles among ntiles (listed behind the tile prefix) */
 		int64_t pairs = 0, cells = 0;
 		int32_t *d_jlist = nullptr, *d_tprefix = nullptr;
 	};
@@ -322,7 +323,9 @@ static int32_t pk_base(const sa_ctx *ctx, int g, int k)
 
 /* Decides which column classes the packed-u16 kernels reproduce exactly (see sa_systolic_pk.inc): profile entries
  * S + const (and the Gotoh first-column tweak) are >= 0, Gotoh q <= 0, and for class K every value of a register stays
- * inside [floor, 65535]: BASE + DELTA + the largest profile entry must fit.  The largest such K is pk_kmax. */
+ * inside [floor, limit]: BASE + DELTA + the largest profile entry must fit.  The largest such K is pk_kmax.  limit =
+ * 65535 for the 16-lane groups; the 8-lane kernels take their three-way maxima with v_pk_maximum3_f16, whose order on
+ * u16 bit patterns is the unsigned order up to 0x7c00: limit = SA_PK_F16_MAX. */
 static void pk_setup(sa_ctx *ctx)
 {
 	const sa_scoring &sc = ctx->sc;
@@ -374,7 +377,7 @@ static void pk_setup(sa_ctx *ctx)
 	ctx->pk_floor = (int32_t)floor_v;
 	const int64_t fixed = floor_v + 4 * (-q) + 4 + pmax + (-q) + extra;
 	for (int k = 1; k <= SA_PK_KMAX; k++) {
-		if ((pk_live(8) + 1) * (gain * 8 * k + slack) + fixed > 65535)
+		if ((pk_live(8) + 1) * (gain * 8 * k + slack) + fixed > SA_PK_F16_MAX) /* (8-lane groups: f16-ordered halves) */
 			break;
 		ctx->pk_kmax = k;
 	}
@@ -838,23 +841,32 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		ccells[(size_t)cls] += (int64_t)n * (lenpre[(size_t)ib] - lenpre[(size_t)ia]);
 	}
 	/* packed classes: consecutive columns of a class share a tile (sa_systolic_pk.inc): rows = the union of their row
-	 * ranges, SA_PK_WPB * 8 streams of `chunk` sequences per workgroup-tile */
+	 * ranges, SA_PK_WPB * 8 streams of `chunk` sequences per workgroup-tile.  The prefix counts the full tiles; the
+	 * partial last tiles follow them in the tile numbering, largest first (their pairs are appended to the prefix). */
+	std::vector<int32_t> nparts((size_t)SA_PLAN_NCLASSES, 0);
 	for (int cls = SA_PK_CLASS0; cls < SA_PLAN_NCLASSES; cls++) {
 		const auto &rw = rows_of[(size_t)cls];
 		if (rw.empty())
 			continue;
 		const int64_t rows = (int64_t)SA_PK_WPB * (cls >= SA_PK16_CLASS0 ? 4 : 8) * plan.chunk_pk;
 		tp[(size_t)cls].push_back(0);
+		std::vector<std::pair<int32_t, int32_t>> parts; /* (rows, pair) */
 		for (size_t c = 0; c < rw.size(); c += 2) {
 			const auto &a = rw[c], &b = rw[c + 1 < rw.size() ? c + 1 : c];
 			const int64_t span = std::max(a.second, b.second) - std::min(a.first, b.first);
-			const int64_t tiles = (span + rows - 1) / rows;
-			if ((int64_t)tp[(size_t)cls].back() + tiles > INT32_MAX) {
+			const int64_t tiles = span / rows;
+			if ((int64_t)tp[(size_t)cls].back() + tiles + (int64_t)parts.size() + 1 > INT32_MAX) {
 				sa_set_error("packed range too large for one launch; split it into smaller ranges");
 				return false;
 			}
 			tp[(size_t)cls].push_back(tp[(size_t)cls].back() + (int32_t)tiles);
+			if (span % rows)
+				parts.emplace_back((int32_t)(span % rows), (int32_t)(c / 2));
 		}
+		std::stable_sort(parts.begin(), parts.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+		for (const auto &pt : parts)
+			tp[(size_t)cls].push_back(pt.second);
+		nparts[(size_t)cls] = (int32_t)parts.size();
 	}
 	bool ok = true;
 	for (int cls = 0; cls < SA_PLAN_NCLASSES && ok; cls++) {
@@ -863,7 +875,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		sa_ctx::ClassLaunch cl;
 		cl.cls = cls;
 		cl.ncols = (int32_t)jl[(size_t)cls].size();
-		cl.ntiles = tp[(size_t)cls].back();
+		cl.npart = nparts[(size_t)cls];
+		cl.ntiles = cl.npart ? tp[(size_t)cls][tp[(size_t)cls].size() - 1 - (size_t)cl.npart] + cl.npart : tp[(size_t)cls].back();
 		cl.pairs = cpairs[(size_t)cls];
 		cl.cells = ccells[(size_t)cls];
 		SA_HIP_CHECK(hipMalloc(&cl.d_jlist, sizeof(int32_t) * jl[(size_t)cls].size()), ok = false);
@@ -1005,6 +1018,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		a.sub8 = ctx->d_sub8;
 		a.jlist = cl.d_jlist;
 		a.tprefix = cl.d_tprefix;
+		a.npart = cl.npart;
 		a.ncols = cl.ncols;
 		a.num = ctx->num;
 		a.start = start;

@@ -79,6 +79,7 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 /* packed-u16 kernels (sa_systolic_pk.inc): 8-lane groups, K = 1..SA_PK_KMAX columns per lane (W = 8 K <= 192), two
  * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
 #define SA_PK_WPB 4
+#define SA_PK_F16_MAX 0x7bff /* largest value of the 8-lane packed kernels: the largest finite f16 bit pattern */
 #define SA_PK_SORT_ROWS 2048 /* rows per arranged block of the row store when a tile is smaller (sa_driver.hip: arranged_store) */
 #define SA_PK_KMAX 24
 #define SA_PK_K_LIST(X) \
@@ -117,6 +118,7 @@ struct SaSysArgs {
 	const int32_t *rowmap;   /* position -> row                                                                 */
 	const int32_t *posmap;   /* row -> position                                                                 */
 	int32_t sort_rows;
+	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
