@@ -44,14 +44,15 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CU x 4 SIMD-32 x 2.4 GHz = 7.86e13 s32 lane-ops/s
 OPS_PER_CELL = {"nw": 5, "ga": 9, "sw": 11}  # reference op counts (nw.c:29-35, ga.c:47-62, sw.c:39-57)
-# SIMD issue cycles one wave64 DP cell costs at the very least with the packed-u16 formulation: per TWO
-# cells NW = 1 plain 32-bit add + 2 v_pk_max_u16, Gotoh = 2 + 4, SW = 3 + 6.  Instruction costs measured on this chip
-# with long kernels against the wall clock (profiles/r02_microbench_nw_chain_dependency_shapes.txt,
-# r02_microbench_valu_rates_wallclock.txt): VOP3 / VOP3P / SDWA / DPP ~4.1 SIMD cycles per wave64 instruction, plain
-# 32-bit VOP2 ~2.5 -- the guide's "2 cycles" row is the plain-VOP2 / v_fma_f32 class.
+# SIMD issue cycles one wave64 DP cell costs at the very least with the packed-u16 formulation of the 8-lane classes
+# (three-way maxima are one v_pk_maximum3_f16): per TWO cells NW = 1 plain 32-bit add + 1 VOP3P,
+# Gotoh = 2 + 3, SW = 3 + 3.5.  Instruction costs measured on this chip with long kernels against the wall clock
+# (profiles/r02_microbench_nw_chain_dependency_shapes.txt, r02_microbench_valu_rates_wallclock.txt,
+# r02i_microbench_max3_f16.txt): VOP3 / VOP3P / SDWA / DPP ~4.1 SIMD cycles per wave64 instruction, plain 32-bit VOP2
+# ~2.5 -- the guide's "2 cycles" row is the plain-VOP2 / v_fma_f32 class.
 CYC_SLOW, CYC_FAST = 4.1, 2.5
-MIN_ISSUE_CYCLES_PER_CELL = {"nw": (1 * CYC_FAST + 2 * CYC_SLOW) / 2, "ga": (2 * CYC_FAST + 4 * CYC_SLOW) / 2,
-                             "sw": (3 * CYC_FAST + 6 * CYC_SLOW) / 2}
+MIN_ISSUE_CYCLES_PER_CELL = {"nw": (1 * CYC_FAST + 1 * CYC_SLOW) / 2, "ga": (2 * CYC_FAST + 3 * CYC_SLOW) / 2,
+                             "sw": (3 * CYC_FAST + 3.5 * CYC_SLOW) / 2}
 SIMDS, SHADER_HZ = 256 * 4, 2.4e9
 CFG4_SHAPE_N = 12_000  # "cfg4 shape": the cfg4 generator and scoring at a size one GPU finishes in a fraction of a second
 

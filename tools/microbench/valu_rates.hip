@@ -55,6 +55,10 @@ template <int MODE> __global__ __launch_bounds__(256) void k(int *out, unsigned 
 			if (MODE == 33) OP8("v_mov_b32_e32 %0, %1", "v"(w));
 			if (MODE == 34) OP8("v_bfe_i32 %0, %1, 8, 8", "v"(w));
 			if (MODE == 35) OP8("v_perm_b32 %0, %1, %0, %2", "v"(w), "v"(acc));
+			if (MODE == 36) OP8("v_cmp_lt_i32_e32 vcc, %1, %0\n\tv_cndmask_b32_e32 %0, %1, %0, vcc", "v"(w) : "vcc");
+			if (MODE == 37) OP8("v_cmp_lt_i32_e64 s[20:21], %1, %0\n\tv_cndmask_b32_e64 %0, %1, %0, s[20:21]", "v"(w) : "s20", "s21");
+			if (MODE == 38) OP8("v_cmp_lt_i32_e32 vcc, %1, %0", "v"(w) : "vcc");
+			if (MODE == 39) OP8("v_sub_u32_e32 %0, %1, %0\n\tv_ashrrev_i32_e32 %0, 31, %0\n\tv_and_b32_e32 %0, %1, %0\n\tv_max_u32_e32 %0, %1, %0", "v"(w));
 		}
 	}
 	unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -119,6 +123,8 @@ int main()
 	ROW(1, "v_add_u32_sdwa"); ROW(18, "v_add_u32_dpp"); ROW(3, "v_mov_b32_dpp"); ROW(11, "v_cndmask_b32");
 	ROW(16, "v_pk_add_i16"); ROW(17, "v_pk_max_i16"); ROW(32, "v_pk_max_f16"); ROW(19, "v_cvt_f32_ubyte1"); ROW(20, "v_dot4c_i32_i8");
 	ROW(34, "v_bfe_i32"); ROW(35, "v_perm_b32");
+	ROW(36, "v_cmp + v_cndmask (vcc), per PAIR"); ROW(37, "v_cmp + v_cndmask (sgpr pair), per PAIR"); ROW(38, "v_cmp_lt_i32 alone");
+	ROW(39, "sub+ashr+and+max select, per FOUR");
 	printf("\n\ncalibration over all launches above: s_memtime %.1f ticks/us of s_memrealtime (100 MHz) = %.0f MHz;  "
 	       "s_memtime %.1f ticks per host-timed us (includes launch ramp, lower bound of the clock);  "
 	       "=> one s_memtime tick is one shader clock at the frequency the chip held (~%.2f GHz), "
