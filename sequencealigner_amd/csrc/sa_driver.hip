@@ -1041,18 +1041,23 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 				 * is one tile; in device memory a block may span several tiles (their stores scatter inside it). */
 				const int ng = 64 / pk_g;
 				const int32_t rows = SA_PK_WPB * ng * ctx->plan->chunk_pk;
-				int32_t block = rows;
-				if (!ctx->out_is_host && rows < SA_PK_SORT_ROWS && SA_PK_SORT_ROWS % rows == 0)
-					block = SA_PK_SORT_ROWS;
-				const sa_ctx::Arranged *ar = nullptr;
-				if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))
-					return 1;
-				if (ar) {
-					a.codes_s = ar->d_codes;
-					a.off_s = ar->d_off;
-					a.rowmap = ar->d_rowmap;
-					a.posmap = ar->d_posmap;
-					a.sort_rows = ar->block;
+				int nl = 0;
+				for (int l = 0; l < SA_PK_SORT_LEVELS; l++) {
+					const int32_t block = SA_PK_SORT_ROWS >> l;
+					if (ctx->out_is_host || block <= rows || block % rows != 0)
+						continue;
+					const sa_ctx::Arranged *ar = nullptr;
+					if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))
+						return 1;
+					if (ar)
+						a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
+				}
+				if (nl < SA_PK_SORT_LEVELS) { /* the tile itself as a block: its scores leave in row order */
+					const sa_ctx::Arranged *ar = nullptr;
+					if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, rows, &ar))
+						return 1;
+					if (ar)
+						a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
 				}
 			}
 		}

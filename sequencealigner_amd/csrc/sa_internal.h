@@ -80,6 +80,7 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
  * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
 #define SA_PK_WPB 4
 #define SA_PK_F16_MAX 0x7bff /* largest value of the 8-lane packed kernels: the largest finite f16 bit pattern */
+#define SA_PK_SORT_LEVELS 4 /* block sizes SA_PK_SORT_ROWS >> level offered to a launch whose tiles are smaller */
 #define SA_PK_SORT_ROWS 2048 /* rows per arranged block of the row store when a tile is smaller (sa_driver.hip: arranged_store) */
 #define SA_PK_KMAX 24
 #define SA_PK_K_LIST(X) \
@@ -112,12 +113,14 @@ struct SaSysArgs {
 	int32_t *long_scratch;   /* strip-mined launch: per wave 2 lines of long_stride/2 ints            */
 	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
 	int32_t pk_base;         /* packed kernels: the constant baseline BASE                                     */
-	/* packed kernels: arranged copy of the store in blocks of sort_rows sequences (0: none), see arranged_store */
-	const uint8_t *codes_s;
-	const int32_t *off_s;    /* num+1 offsets into codes_s by position                                          */
-	const int32_t *rowmap;   /* position -> row                                                                 */
-	const int32_t *posmap;   /* row -> position                                                                 */
-	int32_t sort_rows;
+	/* packed kernels: arranged copies of the store (sa_driver.hip: arranged_store), largest block first; rows = 0: none */
+	struct Arranged {
+		const uint8_t *codes;
+		const int32_t *off;    /* num+1 offsets into codes by position */
+		const int32_t *rowmap; /* position -> row                      */
+		const int32_t *posmap; /* row -> position                      */
+		int32_t rows;          /* sequences per arranged block         */
+	} lv[SA_PK_SORT_LEVELS];
 	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
