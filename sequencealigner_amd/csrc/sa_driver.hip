@@ -1036,6 +1036,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
 			a.delta = pk_delta(ctx, pk_g, pk_k);
 			a.pk_base = pk_base(ctx, pk_g, pk_k);
+			a.out_nt = ctx->out_is_host ? 1 : 0;
 			if (!ctx->env_no_sort) {
 				/* Arranged row streams.  Scores stored straight into host memory must leave in row order: there a block
 				 * is one tile; in device memory a block may span several tiles (their stores scatter inside it). */
@@ -1044,7 +1045,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 				int nl = 0;
 				for (int l = 0; l < SA_PK_SORT_LEVELS; l++) {
 					const int32_t block = SA_PK_SORT_ROWS >> l;
-					if (ctx->out_is_host || block <= rows || block % rows != 0)
+					/* (a tile of SA_PK_ROWS_OWN_BLOCK rows has enough equal lengths of its own, and storing in row order keeps
+					 * the HBM write traffic at the algorithmic 4 bytes per pair) */
+					if (ctx->out_is_host || rows >= SA_PK_ROWS_OWN_BLOCK || block <= rows || block % rows != 0)
 						continue;
 					const sa_ctx::Arranged *ar = nullptr;
 					if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))

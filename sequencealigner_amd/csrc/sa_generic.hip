@@ -158,9 +158,9 @@ __global__ __launch_bounds__(256) void sa_k_pair_per_wave(SaGenericArgs A)
 			score = __shfl(h, (n - 1) & 63, 64); /* M[m][n] sits in the lane owning column n */
 		if (lane == 0) {
 			if (A.out16)
-				__builtin_nontemporal_store((int16_t)score, &reinterpret_cast<int16_t *>(A.out)[q]);
+				reinterpret_cast<int16_t *>(A.out)[q] = (int16_t)score;
 			else
-				__builtin_nontemporal_store(score, &A.out[q]);
+				A.out[q] = score;
 		}
 	}
 }

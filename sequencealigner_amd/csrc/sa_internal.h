@@ -80,6 +80,7 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
  * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
 #define SA_PK_WPB 4
 #define SA_PK_F16_MAX 0x7bff /* largest value of the 8-lane packed kernels: the largest finite f16 bit pattern */
+#define SA_PK_ROWS_OWN_BLOCK 1024 /* tiles of at least this many rows are their own arranged block */
 #define SA_PK_SORT_LEVELS 4 /* block sizes SA_PK_SORT_ROWS >> level offered to a launch whose tiles are smaller */
 #define SA_PK_SORT_ROWS 2048 /* rows per arranged block of the row store when a tile is smaller (sa_driver.hip: arranged_store) */
 #define SA_PK_KMAX 24
@@ -122,6 +123,7 @@ struct SaSysArgs {
 		int32_t rows;          /* sequences per arranged block         */
 	} lv[SA_PK_SORT_LEVELS];
 	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
+	int32_t out_nt;          /* packed kernels: out is host memory, store non-temporally                        */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
