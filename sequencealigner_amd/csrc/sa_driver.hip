@@ -23,7 +23,7 @@
 
 struct sa_ctx {
 	int device = 0;
-	int32_t num = 0, max_len = 0;
+	int32_t num = 0, max_len = 0, min_len = 0;
 	int64_t pairs = 0;
 	sa_scoring sc{};
 	std::vector<sa_meta> meta;     /* device-side (tight) layout: off[k] = sum_{i<k}(len_i+1)          */
@@ -58,6 +58,7 @@ struct sa_ctx {
 	int64_t sys_gain = 0, sys_slack = 0;
 	/* packed-u16 kernels (sa_systolic_pk.inc): column classes K = 1..pk_kmax run there (0: none), see pk_setup */
 	int pk_kmax = 0, pk16_kmax = 0; /* 8-lane groups: K = 1..pk_kmax; 16-lane groups: K = SA_PK_K16_MIN..pk16_kmax */
+	int pk16_f16_kmax = 0;          /* 16-lane groups: classes up to this K fit the f16 range (three-way maxima)      */
 	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0; /* pk_floor: margin below the lowest legitimate value (part of BASE) */
 	int64_t pk_gain = 0, pk_slack = 0, pk_extra = 0;
 	/* arranged copies of the store for the packed kernels' row streams (arranged_store), one per tile shape */
@@ -309,15 +310,16 @@ static int systolic_class_for(int32_t n)
 }
 
 /* frame shifts a value of the packed kernels can see before its last use: its own terminator entering the group plus
- * one per later terminator entering while its last rows travel through the remaining G - 1 = 7 lanes (terminators are
- * at least two stream positions apart) */
-static int pk_live(int g) { return 1 + (g - 1) / 2; } /* 4 for 8-lane groups, 8 for 16-lane groups */
+ * one per later terminator entering while its last rows travel through the remaining G - 1 lanes.  Terminators are
+ * min_len + 1 stream positions apart at least (every sequence is a row of some stream): 4 / 8 shifts for 8- / 16-lane
+ * groups when the store holds a sequence of length 1, one shift when its shortest sequence has >= G - 1 residues. */
+static int pk_live(const sa_ctx *ctx, int g) { return 1 + (g - 1) / (std::max(ctx->min_len, 1) + 1); }
 
 static int32_t pk_delta(const sa_ctx *ctx, int g, int k) { return (int32_t)(ctx->pk_gain * g * k + ctx->pk_slack); }
 static int32_t pk_base(const sa_ctx *ctx, int g, int k)
 {
 	/* (Gotoh: values reach BASE + 3q; SW: the lanes start up to G |e| below the baseline) */
-	return pk_live(g) * pk_delta(ctx, g, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4 +
+	return pk_live(ctx, g) * pk_delta(ctx, g, k) + ctx->pk_floor + 4 * std::abs(ctx->pk_q) + 4 +
 	       (ctx->sc.method == SA_METHOD_SW ? g * std::abs(ctx->sc.gap_ext) : 0);
 }
 
@@ -329,7 +331,7 @@ static int32_t pk_base(const sa_ctx *ctx, int g, int k)
 static void pk_setup(sa_ctx *ctx)
 {
 	const sa_scoring &sc = ctx->sc;
-	ctx->pk_kmax = ctx->pk16_kmax = 0;
+	ctx->pk_kmax = ctx->pk16_kmax = ctx->pk16_f16_kmax = 0;
 	if (!ctx->sys_ok || getenv("SA_HIP_NO_PK"))
 		return;
 	int64_t smax = INT32_MIN, smin = INT32_MAX;
@@ -377,15 +379,18 @@ static void pk_setup(sa_ctx *ctx)
 	ctx->pk_floor = (int32_t)floor_v;
 	const int64_t fixed = floor_v + 4 * (-q) + 4 + pmax + (-q) + extra;
 	for (int k = 1; k <= SA_PK_KMAX; k++) {
-		if ((pk_live(8) + 1) * (gain * 8 * k + slack) + fixed > SA_PK_F16_MAX) /* (8-lane groups: f16-ordered halves) */
+		if ((pk_live(ctx, 8) + 1) * (gain * 8 * k + slack) + fixed > SA_PK_F16_MAX) /* (8-lane groups: f16-ordered halves) */
 			break;
 		ctx->pk_kmax = k;
 	}
 	if (ctx->pk_kmax == SA_PK_KMAX && !getenv("SA_HIP_NO_PK16")) /* wider columns: 16-lane groups, twice as many shifts in flight */
 		for (int k = SA_PK_K16_MIN; k <= SA_PK_KMAX; k++) {
-			if ((pk_live(16) + 1) * (gain * 16 * k + slack) + fixed > 65535)
+			const int64_t top = (pk_live(ctx, 16) + 1) * (gain * 16 * k + slack) + fixed;
+			if (top > 65535)
 				break;
 			ctx->pk16_kmax = k;
+			if (top <= SA_PK_F16_MAX)
+				ctx->pk16_f16_kmax = k;
 		}
 }
 
@@ -407,6 +412,9 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	ctx->device = device;
 	ctx->num = in.num;
 	ctx->max_len = max_len;
+	ctx->min_len = max_len;
+	for (int32_t k = 0; k < in.num; k++)
+		ctx->min_len = std::min<int32_t>(ctx->min_len, (int32_t)in.meta[k].len);
 	ctx->pairs = (int64_t)in.num * (in.num - 1) / 2;
 	ctx->sc = *sc;
 	ctx->meta.resize((size_t)in.num);
@@ -1037,6 +1045,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.delta = pk_delta(ctx, pk_g, pk_k);
 			a.pk_base = pk_base(ctx, pk_g, pk_k);
 			a.out_nt = ctx->out_is_host ? 1 : 0;
+			a.pk_f16 = pk_g == 8 || pk_k <= ctx->pk16_f16_kmax ? 1 : 0;
 			if (!ctx->env_no_sort) {
 				/* Arranged row streams.  Scores stored straight into host memory must leave in row order: there a block
 				 * is one tile; in device memory a block may span several tiles (their stores scatter inside it). */

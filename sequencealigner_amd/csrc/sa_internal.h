@@ -124,6 +124,7 @@ struct SaSysArgs {
 	} lv[SA_PK_SORT_LEVELS];
 	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
 	int32_t out_nt;          /* packed kernels: out is host memory, store non-temporally                        */
+	int32_t pk_f16;          /* packed kernels: the class's values fit SA_PK_F16_MAX (three-way f16 maxima)     */
 	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */

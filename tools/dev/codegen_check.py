@@ -7,7 +7,8 @@ src = f"/root/repo/sequencealigner_amd/csrc/sa_systolic_pk_{m}.hip"
 asm = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-gpu-rdc", "-x", "hip", "--cuda-device-only",
                       "-S", src, "-o", "-"], capture_output=True, text=True).stdout
 g = int(sys.argv[3]) if len(sys.argv) > 3 else 8
-name = f"_ZN12_GLOBAL__N_116sa_k_systolic_pkILi{mi}ELi{g}ELi{k}EEEv9SaSysArgs"
+f16 = (sys.argv[4] == "f16") if len(sys.argv) > 4 else g == 8
+name = f"_ZN12_GLOBAL__N_116sa_k_systolic_pkILi{mi}ELi{g}ELi{k}ELb{int(f16)}EEEv9SaSysArgs"
 body = asm[asm.index(name + ":"):]
 body = body[:body.index("s_endpgm")]
 L = body.split("\n")

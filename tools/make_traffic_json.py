@@ -17,7 +17,7 @@ def collect(sub):
     for f in glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             m = re.search(r"sa_k_systolic<(\d), (\d+), (\d+), (true|false)>", r["Kernel_Name"])
-            mp = re.search(r"sa_k_systolic_pk<(\d), (\d+), (\d+)>", r["Kernel_Name"])
+            mp = re.search(r"sa_k_systolic_pk<(\d), (\d+), (\d+)[,>]", r["Kernel_Name"])
             if mp:
                 name = f"sa_k_systolic_pk{'16' if mp.group(2) == '16' else ''}<{METH[mp.group(1)]},K{mp.group(3)}>"
             elif m:
