@@ -384,7 +384,7 @@ static void pk_setup(sa_ctx *ctx)
 		ctx->pk_kmax = k;
 	}
 	if (ctx->pk_kmax == SA_PK_KMAX && !getenv("SA_HIP_NO_PK16")) /* wider columns: 16-lane groups, twice as many shifts in flight */
-		for (int k = SA_PK_K16_MIN; k <= SA_PK_KMAX; k++) {
+		for (int k = SA_PK_K16_MIN; k <= SA_PK16_KMAX; k++) {
 			const int64_t top = (pk_live(ctx, 16) + 1) * (gain * 16 * k + slack) + fixed;
 			if (top > 65535)
 				break;

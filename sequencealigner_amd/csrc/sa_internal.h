@@ -87,14 +87,18 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 #define SA_PK_K_LIST(X) \
 	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
 	X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
-/* ... and 16-lane groups with K = 13..24 columns per lane for 193..384 columns (one group per DPP row: the 16 lanes of a
- * ds_read_b128 phase are 16 distinct slots, so one profile copy is conflict-free) */
+/* ... and 16-lane groups with K = 13..40 columns per lane for 193..640 columns (one group per DPP row: the 16 lanes of a
+ * ds_read_b128 phase are 16 distinct slots, so one profile copy is conflict-free; K = 40: a 65 KB profile and the last
+ * profile-row offset that still fits the u16 token) */
 #define SA_PK_K16_MIN 13
-#define SA_PK_K16_LIST(X) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
+#define SA_PK16_KMAX 40
+#define SA_PK_K16_LIST(X) \
+	X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) \
+	X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40)
 /* class index space of a plan: [0, SA_SYS_NCLASSES) s32 classes, SA_SYS_CLASS_LONG, then SA_PK_CLASS0 + K (8-lane groups),
  * then SA_PK16_CLASS0 + K (16-lane groups) */
 enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 + SA_PK_KMAX + 1,
-	     SA_PLAN_NCLASSES = SA_PK16_CLASS0 + SA_PK_KMAX + 1 };
+	     SA_PLAN_NCLASSES = SA_PK16_CLASS0 + SA_PK16_KMAX + 1 };
 
 struct SaSysArgs {
 	const uint8_t *codes;    /* encoded store, tight layout: sequence k at off[k], terminator after it */

@@ -25,9 +25,9 @@ def test_class_boundaries_and_padding(method, gaps, sa, oracle):
     for k in range(1, 25):
         lens += [8 * k - 1, 8 * k, 8 * k + 1] if k < 24 else [8 * k - 1, 8 * k]
     lens += [1, 2, 3, 5, 193, 200]  # below the first class; the first 16-lane class
-    for k in range(13, 25):           # 16-lane groups: W = 16 K = 208 .. 384 (the last ones fall to the s32 kernels when
-        lens += [16 * k - 1, 16 * k, 16 * k + 1]  # their DELTA does not fit u16: NW blosum62 gap 4 at K = 24)
-    lens += [400, 513]
+    for k in range(13, 41):           # 16-lane groups: W = 16 K = 208 .. 640 (classes whose range does not fit fall to
+        lens += [16 * k - 1, 16 * k, 16 * k + 1]  # the s32 kernels: with a 1-residue row in the store most of these)
+    lens += [700, 1025]
     seqs = [seq_of(n, 1000 + i) for i, n in enumerate(lens)]
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
@@ -100,10 +100,10 @@ def test_packed_and_s32_kernel_families_agree(sa, monkeypatch):
 def test_frame_budget_follows_the_shortest_sequence(method, gaps, shortest, sa, oracle):
     """The number of frame shifts in flight -- and with it the value range, the choice between the f16 three-way-max
     and the u16 two-way-max form of the 16-lane kernels, and the largest packed class -- follows the store's shortest
-    sequence (sa_driver.hip: pk_live): columns of 193..384 residues against rows whose shortest has 200 / 16 / 7 / 1
+    sequence (sa_driver.hip: pk_live): columns of 193..650 residues against rows whose shortest has 200 / 16 / 7 / 1
     residues (1, 1, 2 and 8 shifts in flight with 16-lane groups), the short rows repeated so that terminators really
     come min_len + 1 positions apart."""
-    seqs = [seq_of(n, 7000 + n) for n in range(200, 385, 3)]
+    seqs = [seq_of(n, 7000 + n) for n in range(200, 385, 3)] + [seq_of(n, 7000 + n) for n in range(390, 660, 13)]
     if shortest < 200:
         seqs = [seq_of(shortest + (i % 2), 300 + i) for i in range(120)] + seqs
     store = sa.SequenceStore.from_sequences(seqs)
