@@ -405,8 +405,13 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	int32_t max_len = 0;
 	if (!validate_and_encode(in, *sc, codes, off, max_len))
 		return nullptr;
+	const bool verbose = getenv("SA_HIP_VERBOSE") != nullptr;
+	const auto t_create = std::chrono::steady_clock::now();
+	auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count(); };
 	if (!device_ready(device))
 		return nullptr;
+	if (verbose)
+		fprintf(stderr, "[seqalign_hip] sa_ctx_create: device ready at %.1f ms\n", since());
 
 	sa_ctx *ctx = new sa_ctx();
 	ctx->device = device;
@@ -472,7 +477,17 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		if (!streams_ok)
 			break;
 		/* code objects are loaded lazily at the first launch: do it here, with the other set-up */
-		SA_HIP_CHECK(sa_warm_kernels(sc->method), break);
+		/* code objects of the kernel families this store's columns fall into (plan_build's class choice) */
+		int families = 0;
+		for (int32_t k = 0; k < in.num; k++) {
+			const int n = in.meta[k].len, k8 = (n + 7) / 8, k16 = (n + 15) / 16;
+			families |= k8 <= ctx->pk_kmax ? SA_WARM_PK8 : (k16 >= SA_PK_K16_MIN && k16 <= ctx->pk16_kmax) ? SA_WARM_PK16 : SA_WARM_S32;
+		}
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_ctx_create: buffers, streams and events at %.1f ms\n", since());
+		SA_HIP_CHECK(sa_warm_kernels(sc->method, families), break);
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_ctx_create: code objects of families %d loaded at %.1f ms\n", families, since());
 		ok = true;
 	} while (0);
 	if (!ok) {

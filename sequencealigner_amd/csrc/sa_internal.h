@@ -139,7 +139,8 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workg
 /* packed-u16 kernels: class K of SA_PK_K_LIST; jlist holds the columns, tprefix the tiles before each column PAIR */
 hipError_t sa_launch_systolic_pk(int method, int g, int k, const SaSysArgs &a, int workgroups, hipStream_t s);
 /* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */
-hipError_t sa_warm_kernels(int method);
+enum : int { SA_WARM_S32 = 1, SA_WARM_PK8 = 2, SA_WARM_PK16 = 4 }; /* kernel families (one code object each per method) */
+hipError_t sa_warm_kernels(int method, int families);
 
 /* ---- launchers implemented in the .hip files ---------------------------- */
 hipError_t sa_launch_generic(int method, const SaGenericArgs &a, int blocks, hipStream_t s);

@@ -19,40 +19,52 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 	}
 }
 
-hipError_t sa_launch_systolic_pk_nw(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);
-hipError_t sa_launch_systolic_pk_ga(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);
-hipError_t sa_launch_systolic_pk_sw(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);
+#define SA_PK_DECL(M)                                                                                  \
+	hipError_t sa_launch_systolic_pk_##M(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);   \
+	hipError_t sa_launch_systolic_pk16_##M(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s); \
+	hipError_t sa_warm_systolic_pk_##M(void);                                                           \
+	hipError_t sa_warm_systolic_pk16_##M(void);                                                         \
+	hipError_t sa_warm_systolic_##M(void);
+SA_PK_DECL(nw)
+SA_PK_DECL(ga)
+SA_PK_DECL(sw)
+#undef SA_PK_DECL
+hipError_t sa_warm_generic(void);
 
 hipError_t sa_launch_systolic_pk(int method, int g, int k, const SaSysArgs &a, int tiles, hipStream_t s)
 {
 	switch (method) {
 	case SA_METHOD_NW:
-		return sa_launch_systolic_pk_nw(g, k, a, tiles, s);
+		return g == 8 ? sa_launch_systolic_pk_nw(g, k, a, tiles, s) : sa_launch_systolic_pk16_nw(g, k, a, tiles, s);
 	case SA_METHOD_GA:
-		return sa_launch_systolic_pk_ga(g, k, a, tiles, s);
+		return g == 8 ? sa_launch_systolic_pk_ga(g, k, a, tiles, s) : sa_launch_systolic_pk16_ga(g, k, a, tiles, s);
 	case SA_METHOD_SW:
-		return sa_launch_systolic_pk_sw(g, k, a, tiles, s);
+		return g == 8 ? sa_launch_systolic_pk_sw(g, k, a, tiles, s) : sa_launch_systolic_pk16_sw(g, k, a, tiles, s);
 	default:
 		return hipErrorInvalidValue;
 	}
 }
 
-hipError_t sa_warm_systolic_pk_nw(void);
-hipError_t sa_warm_systolic_pk_ga(void);
-hipError_t sa_warm_systolic_pk_sw(void);
-hipError_t sa_warm_systolic_nw(void);
-hipError_t sa_warm_systolic_ga(void);
-hipError_t sa_warm_systolic_sw(void);
-hipError_t sa_warm_generic(void);
-
-hipError_t sa_warm_kernels(int method)
+/* Loads the code objects of the kernel families a store will use (SA_WARM_*), outside any timed phase.  A family that is
+ * not warmed still works: its code object loads at its first launch. */
+hipError_t sa_warm_kernels(int method, int families)
 {
-	hipError_t e = method == SA_METHOD_NW ? sa_warm_systolic_nw() : method == SA_METHOD_GA ? sa_warm_systolic_ga() : sa_warm_systolic_sw();
-	if (e == hipSuccess && method == SA_METHOD_NW)
-		e = sa_warm_systolic_pk_nw();
-	if (e == hipSuccess && method == SA_METHOD_GA)
-		e = sa_warm_systolic_pk_ga();
-	if (e == hipSuccess && method == SA_METHOD_SW)
-		e = sa_warm_systolic_pk_sw();
-	return e != hipSuccess ? e : sa_warm_generic();
+	hipError_t e = sa_warm_generic(); /* pair-per-wave fallback, expand, widen, filter: small */
+#define SA_WARM(M)                                                      \
+	do {                                                            \
+		if (e == hipSuccess && (families & SA_WARM_S32))        \
+			e = sa_warm_systolic_##M();                     \
+		if (e == hipSuccess && (families & SA_WARM_PK8))        \
+			e = sa_warm_systolic_pk_##M();                  \
+		if (e == hipSuccess && (families & SA_WARM_PK16))       \
+			e = sa_warm_systolic_pk16_##M();                \
+	} while (0)
+	if (method == SA_METHOD_NW)
+		SA_WARM(nw);
+	else if (method == SA_METHOD_GA)
+		SA_WARM(ga);
+	else
+		SA_WARM(sw);
+#undef SA_WARM
+	return e;
 }
