@@ -446,13 +446,19 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		SA_HIP_CHECK(hipMalloc(&ctx->d_codes, codes.size()), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_meta, sizeof(sa_meta) * (size_t)in.num), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_sub, sizeof(sc->sub)), break);
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_ctx_create: first allocations at %.1f ms\n", since());
 		SA_HIP_CHECK(hipMemcpy(ctx->d_codes, codes.data(), codes.size(), hipMemcpyHostToDevice), break);
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_ctx_create: first upload at %.1f ms\n", since());
 		SA_HIP_CHECK(hipMemcpy(ctx->d_meta, ctx->meta.data(), sizeof(sa_meta) * (size_t)in.num, hipMemcpyHostToDevice), break);
 		SA_HIP_CHECK(hipMemcpy(ctx->d_sub, sc->sub, sizeof(sc->sub), hipMemcpyHostToDevice), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_off, sizeof(int32_t) * off.size()), break);
 		SA_HIP_CHECK(hipMemcpy(ctx->d_off, off.data(), sizeof(int32_t) * off.size(), hipMemcpyHostToDevice), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_sub8, sizeof(sub8)), break);
 		SA_HIP_CHECK(hipMemcpy(ctx->d_sub8, sub8, sizeof(sub8), hipMemcpyHostToDevice), break);
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_ctx_create: uploads at %.1f ms\n", since());
 
 		/* strip-boundary scratch of the pair-per-wave kernels: 2*(max+2) ints per resident wave */
 		hipDeviceProp_t prop;
@@ -465,6 +471,8 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		ctx->generic_blocks = (int)blocks;
 		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * sa_ctx::COUNTER_SLOTS * sa_ctx::COUNTERS_PER_SLOT), break);
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_ctx_create: scratch at %.1f ms\n", since());
 		ctx->persistent_wgs = prop.multiProcessorCount * 32;
 		bool streams_ok = true;
 		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming), streams_ok = false);
