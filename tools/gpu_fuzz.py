@@ -24,7 +24,7 @@ while time.time() - t0 < budget:
     else:
         gaps = dict(gap_open=int(rng.choice([0, 1, 2, 5, 10, 11, 12, 16, 25, 60, 120])), gap_extend=int(rng.choice([0, 1, 2, 3, 5, 10, 20])))
     n = int(rng.integers(2, 400))
-    regime = int(rng.integers(0, 6))
+    regime = int(rng.integers(0, 7))
     if regime == 0:
         lens = rng.integers(1, 10, n)
     elif regime == 1:
@@ -35,6 +35,10 @@ while time.time() - t0 < budget:
         lens = np.where(rng.random(n) < 0.5, 1, rng.integers(100, 140, n))
     elif regime == 4:
         lens = np.full(n, int(rng.integers(1, 260)))
+    elif regime == 6:  # the frame budget follows the shortest sequence: short rows of a chosen length against wide columns
+        m = int(rng.choice([2, 3, 5, 8, 14, 15, 16, 31, 63]))
+        nn = min(n, 150)
+        lens = np.where(rng.random(nn) < 0.5, m + rng.integers(0, 3, nn), rng.integers(150, 660, nn))
     else:
         lens = np.where(rng.random(min(n, 80)) < 0.1, rng.integers(1000, 2300, min(n, 80)), rng.integers(1, 150, min(n, 80)))
     alpha = NT if dna else AA
