@@ -983,6 +983,62 @@ extern "C" int sa_hip_widen16(const int16_t *d_src, int32_t *d_dst, int64_t coun
 	return 0;
 }
 
+/* Arranged row streams of one packed launch of the current plan (builds the copies it needs on first use).  Scores
+ * stored straight into host memory must leave in row order: there a block is one tile; in device memory a block may
+ * span several tiles (their stores scatter inside it). */
+static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, SaSysArgs &a)
+{
+	if (ctx->env_no_sort)
+		return true;
+	const int ng = 64 / pk_g;
+	const int32_t rows = SA_PK_WPB * ng * ctx->plan->chunk_pk;
+	int nl = 0;
+	for (int l = 0; l < SA_PK_SORT_LEVELS; l++) {
+		const int32_t block = SA_PK_SORT_ROWS >> l;
+		/* (a tile of SA_PK_ROWS_OWN_BLOCK rows has enough equal lengths of its own, and storing in row order keeps
+		 * the HBM write traffic at the algorithmic 4 bytes per pair) */
+		if (ctx->out_is_host || rows >= SA_PK_ROWS_OWN_BLOCK || block <= rows || block % rows != 0)
+			continue;
+		const sa_ctx::Arranged *ar = nullptr;
+		if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))
+			return false;
+		if (ar)
+			a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
+	}
+	if (nl < SA_PK_SORT_LEVELS) { /* the tile itself as a block: its scores leave in row order */
+		const sa_ctx::Arranged *ar = nullptr;
+		if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, rows, &ar))
+			return false;
+		if (ar)
+			a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
+	}
+	return true;
+}
+
+/* Host-side preparation of a range's launches -- the plan and the arranged copies of the store -- so that a caller
+ * that times the launch/copy loop (sa_ctx_align_host) can do it with its other set-up: like the uploads, it is input
+ * preparation, not alignment.  Idempotent; align_range_impl does the same on demand. */
+static bool prepare_range(sa_ctx *ctx, int64_t start, int64_t count, bool host_out)
+{
+	if (count <= 0)
+		return true;
+	if (!plan_build(ctx, start, count))
+		return false;
+	const bool was = ctx->out_is_host;
+	ctx->out_is_host = host_out;
+	bool ok = true;
+	for (const auto &cl : ctx->plan->classes) {
+		if (cl.cls < SA_PK_CLASS0)
+			continue;
+		SaSysArgs a{};
+		ok = pk_arranged_levels(ctx, cl.cls >= SA_PK16_CLASS0 ? 16 : 8, a);
+		if (!ok)
+			break;
+	}
+	ctx->out_is_host = was;
+	return ok;
+}
+
 static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16)
 {
 	if (!ctx || start < 0 || count < 0 || start + count > ctx->pairs || (!d_scores && count)) {
@@ -1069,32 +1125,8 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.pk_base = pk_base(ctx, pk_g, pk_k);
 			a.out_nt = ctx->out_is_host ? 1 : 0;
 			a.pk_f16 = pk_g == 8 || pk_k <= ctx->pk16_f16_kmax ? 1 : 0;
-			if (!ctx->env_no_sort) {
-				/* Arranged row streams.  Scores stored straight into host memory must leave in row order: there a block
-				 * is one tile; in device memory a block may span several tiles (their stores scatter inside it). */
-				const int ng = 64 / pk_g;
-				const int32_t rows = SA_PK_WPB * ng * ctx->plan->chunk_pk;
-				int nl = 0;
-				for (int l = 0; l < SA_PK_SORT_LEVELS; l++) {
-					const int32_t block = SA_PK_SORT_ROWS >> l;
-					/* (a tile of SA_PK_ROWS_OWN_BLOCK rows has enough equal lengths of its own, and storing in row order keeps
-					 * the HBM write traffic at the algorithmic 4 bytes per pair) */
-					if (ctx->out_is_host || rows >= SA_PK_ROWS_OWN_BLOCK || block <= rows || block % rows != 0)
-						continue;
-					const sa_ctx::Arranged *ar = nullptr;
-					if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))
-						return 1;
-					if (ar)
-						a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
-				}
-				if (nl < SA_PK_SORT_LEVELS) { /* the tile itself as a block: its scores leave in row order */
-					const sa_ctx::Arranged *ar = nullptr;
-					if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, rows, &ar))
-						return 1;
-					if (ar)
-						a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
-				}
-			}
+			if (!pk_arranged_levels(ctx, pk_g, a))
+				return 1;
 		}
 		a.counter = counters + cl.cls;
 		a.chunk = is_pk ? ctx->plan->chunk_pk : is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
@@ -1626,6 +1658,8 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 				if (!grow(d.h_stage[k], d.stage_elems[k], batch, true))
 					return 1;
 	}
+	if (direct && !prepare_range(ctx, start, total, true))
+		return 1;
 	SA_HIP_CHECK(hipDeviceSynchronize(), return 1);
 
 	/* ---- the launch/copy loop: what the reference brackets with bench_align_start/end ---- */
