@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 2
+#define SA_ABI_VERSION 3
 
 /* ---- data types shared with the reference ------------------------------- */
 
@@ -154,6 +154,20 @@ int sa_hip_host_unregister(void *p);
 int sa_ctx_scores_fit16(const sa_ctx *ctx);
 int sa_ctx_align_range16(sa_ctx *ctx, int64_t start, int64_t count, int16_t *d_scores, void *stream);
 int sa_hip_widen16(const int16_t *d_src, int32_t *d_dst, int64_t count, void *stream);
+
+/* Tile-interleaved sharding for one process per GPU (no reference counterpart: SURVEY 8e; replaces the contiguous
+ * range abstraction `kernel(scores, start, batch)` of src/bio/kernels.cu:32-40 in the multi-GPU path).  The launch
+ * plan of the packed range [start, start+count) -- the largest-first list of workgroup-tiles of every column-length
+ * class -- is the same on every rank; its tiles are dealt over `world` ranks by accumulated DP work, so every rank
+ * keeps full-size tiles and whole arranged row blocks.  Rank `rank` scores its tiles and stores them densely, in tile
+ * order, into d_share: sa_ctx_share_elems() elements (the same on every rank) of int16 (elem16 != 0; needs
+ * sa_ctx_scores_fit16) or s32.  After an all-gather of the shares (rank-major, world x share_elems elements),
+ * sa_ctx_place_shares widens and places them: d_packed[p - start] = score of pair p, the reference's packed order
+ * (src/io/output.c:83).  world = 1 is allowed (one share holding every tile).  All asynchronous on `stream`. */
+int64_t sa_ctx_share_elems(sa_ctx *ctx, int64_t start, int64_t count, int world);
+int sa_ctx_align_share(sa_ctx *ctx, int64_t start, int64_t count, int world, int rank, void *d_share, int elem16, void *stream);
+int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, int world, const void *d_shares, int elem16,
+			int32_t *d_packed, void *stream);
 
 /* Packed triangular (device) -> full symmetric dim x dim with zero diagonal
  * (device), the layout of src/io/output.c:76-81.  Asynchronous on `stream`. */

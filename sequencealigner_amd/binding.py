@@ -51,6 +51,7 @@ ABI_SYMBOLS = (
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
+    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares",
 )
 
 
@@ -144,6 +145,12 @@ def load_library() -> C.CDLL:
     lib.sa_hip_host_register.restype = C.c_int
     lib.sa_hip_host_unregister.argtypes = [C.c_void_p]
     lib.sa_hip_host_unregister.restype = C.c_int
+    lib.sa_ctx_share_elems.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    lib.sa_ctx_share_elems.restype = C.c_int64
+    lib.sa_ctx_align_share.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.sa_ctx_align_share.restype = C.c_int
+    lib.sa_ctx_place_shares.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.sa_ctx_place_shares.restype = C.c_int
     _lib = lib
     return lib
 
@@ -410,6 +417,25 @@ class Context:
     def widen16(self, d_src16_ptr: int, d_dst32_ptr: int, count: int, stream: int = 0) -> None:
         """int16 exchange format -> the reference's s32, on the device"""
         if self._lib.sa_hip_widen16(C.c_void_p(d_src16_ptr), C.c_void_p(d_dst32_ptr), count, C.c_void_p(stream)):
+            raise AlignError(_err())
+
+    # ---- tile-interleaved sharding (one process per GPU; sequencealigner_amd/distributed.py: TiledGatherStep) ----
+    def share_elems(self, start: int, count: int, world: int) -> int:
+        """elements of one rank's dense share of the packed range (the same on every rank)"""
+        v = int(self._lib.sa_ctx_share_elems(self._h, start, count, world))
+        if v < 0:
+            raise AlignError(_err())
+        return v
+
+    def align_share(self, start: int, count: int, world: int, rank: int, d_share_ptr: int, elem16: bool, stream: int = 0) -> None:
+        """scores of `rank`'s tiles of the range, densely in tile order (int16 or s32 elements)"""
+        if self._lib.sa_ctx_align_share(self._h, start, count, world, rank, C.c_void_p(d_share_ptr), int(elem16), C.c_void_p(stream)):
+            raise AlignError(_err())
+
+    def place_shares(self, start: int, count: int, world: int, d_shares_ptr: int, elem16: bool, d_packed_ptr: int, stream: int = 0) -> None:
+        """gathered shares (rank-major) -> d_packed[p - start], the reference's packed order, widened to s32"""
+        if self._lib.sa_ctx_place_shares(self._h, start, count, world, C.c_void_p(d_shares_ptr), int(elem16),
+                                         C.c_void_p(d_packed_ptr), C.c_void_p(stream)):
             raise AlignError(_err())
 
     def align_host(self, matrix: Optional[np.ndarray], triangular: bool, start: int = 0, count: Optional[int] = None) -> float:

@@ -21,6 +21,16 @@
 #include <atomic>
 #include <chrono>
 
+/* The class launches of a range run concurrently, one stream each; the HIP runtime multiplexes streams onto
+ * GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's), and kernels that share a queue run one
+ * after the other: with the default, cfg 2's six classes ran as two rounds of three, each round with its own tail
+ * (profiles/r03a_*).  The variable is read when the runtime initialises, so it is set when this library is loaded --
+ * unless the user has set it. */
+__attribute__((constructor)) static void sa_runtime_knobs(void)
+{
+	setenv("GPU_MAX_HW_QUEUES", "12", 0);
+}
+
 struct sa_ctx {
 	int device = 0;
 	int32_t num = 0, max_len = 0, min_len = 0;
@@ -40,7 +50,7 @@ struct sa_ctx {
 	/* tile counters of the persistent launches: one slot of (classes + 1) counters per sa_ctx_align_range
 	 * call, taken round-robin from a ring so that ranges issued back to back on DIFFERENT streams (an
 	 * overlapped multi-chunk schedule) never share a counter */
-	enum { COUNTER_SLOTS = 256, COUNTERS_PER_SLOT = SA_PLAN_NCLASSES };
+	enum { COUNTER_SLOTS = 256, COUNTERS_PER_SLOT = 2 * SA_PLAN_NCLASSES }; /* (next tile, workgroups done) per class */
 	unsigned *d_counters = nullptr;
 	uint64_t call_no = 0;
 	hipEvent_t slot_done[COUNTER_SLOTS] = {}; /* recorded after the launches that used a slot: its next user waits */
@@ -49,7 +59,7 @@ struct sa_ctx {
 	int long_wgs = 0;
 	int persistent_wgs = 0;         /* workgroups of a persistent systolic launch  */
 	/* the class launches of one range run concurrently on side streams (their tails overlap) */
-	enum { NSIDE = 4 };
+	enum { NSIDE = 8 };
 	hipStream_t side[NSIDE] = {};
 	hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {};
 	/* systolic fast path: parameters and validity (see systolic_setup) */
@@ -78,6 +88,12 @@ struct sa_ctx {
 		int32_t npart = 0; /* packed classes: partial tiles among ntiles (listed behind the tile prefix) */
 		int64_t pairs = 0, cells = 0;
 		int32_t *d_jlist = nullptr, *d_tprefix = nullptr;
+		/* share plans (tile-interleaved sharding): the tiles of rank 0, rank 1, ... back to back; rank r runs
+		 * d_tlist[rank_first[r] .. rank_first[r + 1]) and stores tile t at d_doff[t] of its dense share */
+		int32_t *d_tlist = nullptr;
+		int64_t *d_doff = nullptr;
+		std::vector<int32_t> rank_first;
+		std::vector<int64_t> rank_pairs, rank_cells;
 	};
 	struct Plan {
 		int64_t start = -1, count = -1;
@@ -86,6 +102,26 @@ struct sa_ctx {
 		std::vector<ClassLaunch> classes;
 		std::vector<std::pair<int64_t, int64_t>> generic; /* (start, count) runs for the generic kernels */
 		uint64_t stamp = 0;
+		/* share plans: world > 0.  Every rank's dense share is share_elems elements long (the longest one's length);
+		 * segs places the gathered shares (rank-major) into packed order */
+		int world = 0;
+		int64_t share_elems = 0;
+		SaPlaceSeg *d_segs = nullptr;
+		int32_t nsegs = 0;
+		struct GenericShare {
+			int64_t start, count, doff;
+		};
+		/* the packed classes are launched in bundles (sa_internal.h: SaPkClassArgs): classes of one lane-group width,
+		 * one block of SA_PK_BUNDLE consecutive K and one maxima form, walked by decreasing K */
+		struct PkLaunch {
+			int g = 8, klo = 1, f16 = 1, kmax = 1;
+			std::vector<int> cls;          /* indices into `classes`, walking order                       */
+			SaPkClassArgs *d_args = nullptr; /* max(world, 1) arrays of cls.size() entries, rank-major     */
+			std::vector<int32_t> nlocal;   /* tiles of the launch, per rank (one entry when world == 0)   */
+			std::vector<int64_t> pairs, cells;
+		};
+		std::vector<PkLaunch> pk_launches;
+		std::vector<std::vector<GenericShare>> generic_share; /* [rank]: sub-runs of the generic runs */
 	};
 	std::vector<Plan> plans;  /* small LRU cache */
 	Plan *plan = nullptr;     /* plan of the current sa_ctx_align_range call */
@@ -123,7 +159,12 @@ static void plan_free(sa_ctx::Plan &pl)
 	for (auto &c : pl.classes) {
 		(void)hipFree(c.d_jlist);
 		(void)hipFree(c.d_tprefix);
+		(void)hipFree(c.d_tlist);
+		(void)hipFree(c.d_doff);
 	}
+	(void)hipFree(pl.d_segs);
+	for (auto &b : pl.pk_launches)
+		(void)hipFree(b.d_args);
 	pl = sa_ctx::Plan();
 }
 
@@ -471,6 +512,7 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		ctx->generic_blocks = (int)blocks;
 		SA_HIP_CHECK(hipMalloc(&ctx->d_scratch, (size_t)(blocks * per_block)), break);
 		SA_HIP_CHECK(hipMalloc(&ctx->d_counters, sizeof(unsigned) * sa_ctx::COUNTER_SLOTS * sa_ctx::COUNTERS_PER_SLOT), break);
+		SA_HIP_CHECK(hipMemset(ctx->d_counters, 0, sizeof(unsigned) * sa_ctx::COUNTER_SLOTS * sa_ctx::COUNTERS_PER_SLOT), break);
 		if (verbose)
 			fprintf(stderr, "[seqalign_hip] sa_ctx_create: scratch at %.1f ms\n", since());
 		ctx->persistent_wgs = prop.multiProcessorCount * 32;
@@ -780,10 +822,14 @@ extern "C" int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64
 
 /* ---- launch planning for a packed range ------------------------------------------------- */
 
-static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
+static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool host_out, SaSysArgs &a);
+
+/* world = 0: the plan of sa_ctx_align_range (every tile, packed order).  world >= 1: a SHARE plan -- the same tile lists
+ * dealt over `world` ranks, dense tile-order output, placement segments (sa_ctx_align_share / sa_ctx_place_shares). */
+static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 {
 	for (auto &pl : ctx->plans)
-		if (pl.start == start && pl.count == count) {
+		if (pl.start == start && pl.count == count && pl.world == world) {
 			pl.stamp = ++ctx->plan_clock;
 			ctx->plan = &pl;
 			return true;
@@ -813,8 +859,9 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 	 * shorter streams so that there are still several tiles per wave slot. */
 	{
 		const int64_t want_tiles = (int64_t)ctx->persistent_wgs * 6;
+		const int64_t mine = world > 1 ? count / world : count; /* pairs one rank runs */
 		int32_t chunk = SA_SYS_CHUNK;
-		while (chunk > 8 && count / (4 * chunk) < want_tiles)
+		while (chunk > 8 && mine / (4 * chunk) < want_tiles)
 			chunk >>= 1;
 		if (ctx->env_chunk)
 			chunk = ctx->env_chunk;
@@ -824,7 +871,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		 * share at 8 GPUs, a super-chunk) still drains evenly */
 		const int64_t want_pk = (int64_t)ctx->persistent_wgs; /* = 32 x CUs = 8 x (4 workgroups per CU) */
 		int32_t cpk = SA_SYS_CHUNK;
-		while (cpk > 4 && count / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < want_pk)
+		while (cpk > 4 && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < want_pk)
 			cpk >>= 1;
 		if (ctx->env_chunk)
 			cpk = ctx->env_chunk;
@@ -924,9 +971,251 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 		}
 		plan.classes.push_back(cl);
 	}
+	/* launch order: the class with the most DP work first -- the class launches of a range run side by side, and the
+	 * short ones fill the machine while the long ones taper off */
+	std::stable_sort(plan.classes.begin(), plan.classes.end(),
+			 [](const sa_ctx::ClassLaunch &x, const sa_ctx::ClassLaunch &y) { return x.cells > y.cells; });
 	plan.start = start;
 	plan.count = count;
+	plan.world = world;
 	plan.stamp = ++ctx->plan_clock;
+	/* ---- share plan: deal the tiles of every class over the ranks, lay out the dense shares, list the placement ---- */
+	if (ok && world >= 1) {
+		/* One list for the whole job, the same on every rank: classes in order, inside a class the launch's own tile
+		 * order (full tiles, then the partial ones by decreasing size).  A tile goes to the rank with the least
+		 * accumulated work so far (cost = row residues x per-step instruction weight of the class): the shares end
+		 * within one small partial tile of each other, every rank keeps full-size tiles and whole arranged blocks. */
+		std::vector<int64_t> load((size_t)world, 0), fill((size_t)world, 0);
+		struct Geo {
+			int32_t cls_idx, t, owner;
+			int32_t j[2], ia[2], ib[2], i_begin, i_count;
+			bool dup;
+			const int32_t *rowmap;
+			int64_t doff;
+		};
+		std::vector<Geo> geo;
+		for (size_t ci = 0; ci < plan.classes.size() && ok; ci++) {
+			auto &cl = plan.classes[ci];
+			const int cls = cl.cls;
+			const bool is_pk = cls >= SA_PK_CLASS0;
+			const int pk_g = cls >= SA_PK16_CLASS0 ? 16 : 8;
+			const int G = is_pk ? pk_g : cls == SA_SYS_CLASS_LONG ? 64 : SA_SYS_CLASSES[cls].G;
+			const int K = is_pk ? cls - (pk_g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0) : cls == SA_SYS_CLASS_LONG ? 16 : SA_SYS_CLASSES[cls].K;
+			const int64_t weight = (int64_t)(K + 6) * (G / 8);
+			const auto &J = jl[(size_t)cls];
+			const auto &T = tp[(size_t)cls];
+			std::vector<Geo> tiles((size_t)cl.ntiles);
+			if (is_pk) {
+				SaSysArgs a{};
+				if (!pk_arranged_levels(ctx, pk_g, plan.chunk_pk, false, a)) {
+					ok = false;
+					break;
+				}
+				const int32_t lvrows[SA_PK_SORT_LEVELS] = { a.lv[0].rows, a.lv[1].rows, a.lv[2].rows, a.lv[3].rows };
+				const int32_t rows = SA_PK_WPB * (64 / pk_g) * plan.chunk_pk;
+				const auto &rw = rows_of[(size_t)cls];
+				const int32_t npairs = (cl.ncols + 1) / 2, nfull = T[(size_t)npairs];
+				for (int32_t t = 0; t < cl.ntiles; t++) {
+					int32_t lo;
+					if (t < nfull)
+						lo = (int32_t)(std::upper_bound(T.begin(), T.begin() + npairs + 1, t) - T.begin()) - 1;
+					else
+						lo = T[(size_t)(npairs + 1 + (t - nfull))];
+					const size_t c0 = (size_t)2 * lo, c1 = c0 + 1 < rw.size() ? c0 + 1 : c0;
+					Geo &g = tiles[(size_t)t];
+					g.dup = c1 == c0;
+					g.j[0] = J[c0], g.j[1] = J[c1];
+					g.ia[0] = rw[c0].first, g.ib[0] = rw[c0].second;
+					g.ia[1] = rw[c1].first, g.ib[1] = rw[c1].second;
+					const int32_t ra = std::min(g.ia[0], g.ia[1]), rb = std::max(g.ib[0], g.ib[1]);
+					const int32_t chunk = t < nfull ? t - T[(size_t)lo] : T[(size_t)lo + 1] - T[(size_t)lo];
+					g.i_begin = ra + chunk * rows;
+					g.i_count = std::min(rows, rb - g.i_begin);
+					const int l = sa_pk_pick_level(lvrows, ra, rb, g.i_begin, rows);
+					g.rowmap = l >= 0 ? a.lv[l].rowmap : nullptr;
+				}
+			} else {
+				const int rows = cls == SA_SYS_CLASS_LONG ? SA_SYS_WPB(64, true) * std::min(plan.chunk, 16)
+									   : SA_SYS_WPB(G, false) * (64 / G) * plan.chunk;
+				for (int32_t k = 0; k < cl.ncols; k++) {
+					const int32_t j = J[(size_t)k];
+					const int64_t tri = (int64_t)j * (j - 1) / 2;
+					const int32_t ia = (int32_t)std::max<int64_t>(0, start - tri), ib = (int32_t)std::min<int64_t>(j, end - tri);
+					for (int32_t t = T[(size_t)k]; t < T[(size_t)k + 1]; t++) {
+						Geo &g = tiles[(size_t)t];
+						g.dup = true; /* one column, one run */
+						g.j[0] = g.j[1] = j;
+						g.ia[0] = g.ia[1] = ia, g.ib[0] = g.ib[1] = ib;
+						g.i_begin = ia + (t - T[(size_t)k]) * rows;
+						g.i_count = std::min(rows, ib - g.i_begin);
+						g.rowmap = nullptr;
+					}
+				}
+			}
+			std::vector<std::vector<int32_t>> mine((size_t)world);
+			std::vector<int64_t> doff((size_t)cl.ntiles, 0);
+			cl.rank_pairs.assign((size_t)world, 0);
+			cl.rank_cells.assign((size_t)world, 0);
+			for (int32_t t = 0; t < cl.ntiles; t++) {
+				Geo &g = tiles[(size_t)t];
+				/* (arranged tiles hold a permutation of their block's rows: the residue count of the position range is that
+				 * of the rows only when the tile is its whole block -- close enough for a load estimate) */
+				const int64_t res = lenpre[(size_t)(g.i_begin + g.i_count)] - lenpre[(size_t)g.i_begin] + g.i_count;
+				int r = 0;
+				for (int q = 1; q < world; q++)
+					if (load[(size_t)q] < load[(size_t)r])
+						r = q;
+				load[(size_t)r] += res * weight;
+				g.cls_idx = (int32_t)ci;
+				g.t = t;
+				g.owner = r;
+				g.doff = fill[(size_t)r];
+				doff[(size_t)t] = g.doff;
+				fill[(size_t)r] += (int64_t)(g.dup ? 1 : 2) * SA_SHARE_PAD(g.i_count);
+				mine[(size_t)r].push_back(t);
+				for (int h = 0; h < (g.dup ? 1 : 2); h++) {
+					const int64_t lo_i = std::max(g.ia[h], g.i_begin), hi_i = std::min(g.ib[h], g.i_begin + g.i_count);
+					if (hi_i > lo_i) {
+						cl.rank_pairs[(size_t)r] += hi_i - lo_i;
+						cl.rank_cells[(size_t)r] += (int64_t)ctx->meta[(size_t)g.j[h]].len * (lenpre[(size_t)hi_i] - lenpre[(size_t)lo_i]);
+					}
+				}
+				geo.push_back(g);
+			}
+			std::vector<int32_t> tl;
+			cl.rank_first.assign((size_t)world + 1, 0);
+			for (int r = 0; r < world; r++) {
+				tl.insert(tl.end(), mine[(size_t)r].begin(), mine[(size_t)r].end());
+				cl.rank_first[(size_t)r + 1] = (int32_t)tl.size();
+			}
+			SA_HIP_CHECK(hipMalloc(&cl.d_tlist, sizeof(int32_t) * std::max<size_t>(tl.size(), 1)), ok = false);
+			if (ok) {
+				SA_HIP_CHECK(hipMalloc(&cl.d_doff, sizeof(int64_t) * std::max<size_t>(doff.size(), 1)), ok = false);
+			}
+			if (ok && !tl.empty()) {
+				SA_HIP_CHECK(hipMemcpy(cl.d_tlist, tl.data(), sizeof(int32_t) * tl.size(), hipMemcpyHostToDevice), ok = false);
+			}
+			if (ok && !doff.empty()) {
+				SA_HIP_CHECK(hipMemcpy(cl.d_doff, doff.data(), sizeof(int64_t) * doff.size(), hipMemcpyHostToDevice), ok = false);
+			}
+		}
+		/* what no systolic class covers: every run of the pair-per-wave kernels is cut into `world` equal pieces */
+		plan.generic_share.assign((size_t)world, {});
+		for (const auto &run : plan.generic) {
+			const int64_t per = (run.second + world - 1) / world;
+			for (int r = 0; r < world; r++) {
+				const int64_t lo_p = std::min(run.second, (int64_t)r * per), hi_p = std::min(run.second, lo_p + per);
+				if (hi_p <= lo_p)
+					continue;
+				plan.generic_share[(size_t)r].push_back({ run.first + lo_p, hi_p - lo_p, fill[(size_t)r] });
+				fill[(size_t)r] += SA_SHARE_PAD(hi_p - lo_p);
+			}
+		}
+		plan.share_elems = std::max<int64_t>(8, *std::max_element(fill.begin(), fill.end()));
+		/* placement: one segment per run of a tile, pieces of the generic sub-runs */
+		std::vector<SaPlaceSeg> segs;
+		for (const Geo &g : geo)
+			for (int h = 0; h < (g.dup ? 1 : 2); h++) {
+				SaPlaceSeg sg{};
+				sg.src = (int64_t)g.owner * plan.share_elems + g.doff + (int64_t)h * SA_SHARE_PAD(g.i_count);
+				sg.dst = (int64_t)g.j[h] * (g.j[h] - 1) / 2 - start;
+				sg.rowmap = g.rowmap;
+				sg.count = g.i_count;
+				sg.pos0 = g.i_begin;
+				sg.ia = g.ia[h];
+				sg.ib = g.ib[h];
+				segs.push_back(sg);
+			}
+		for (int r = 0; r < world; r++)
+			for (const auto &gs : plan.generic_share[(size_t)r])
+				for (int64_t o = 0; o < gs.count; o += 8192) {
+					SaPlaceSeg sg{};
+					sg.src = (int64_t)r * plan.share_elems + gs.doff + o;
+					sg.dst = gs.start + o - start;
+					sg.rowmap = nullptr;
+					sg.count = (int32_t)std::min<int64_t>(8192, gs.count - o);
+					sg.pos0 = 0;
+					sg.ia = 0;
+					sg.ib = sg.count;
+					segs.push_back(sg);
+				}
+		plan.nsegs = (int32_t)segs.size();
+		if (ok && !segs.empty()) {
+			SA_HIP_CHECK(hipMalloc(&plan.d_segs, sizeof(SaPlaceSeg) * segs.size()), ok = false);
+			if (ok) {
+				SA_HIP_CHECK(hipMemcpy(plan.d_segs, segs.data(), sizeof(SaPlaceSeg) * segs.size(), hipMemcpyHostToDevice), ok = false);
+			}
+		}
+	}
+	/* ---- packed classes -> bundle launches ---- */
+	if (ok) {
+		const int nranks = std::max(world, 1);
+		std::vector<int> order; /* packed classes by decreasing K inside their bundle: the launch ends on its cheapest tiles */
+		for (size_t ci = 0; ci < plan.classes.size(); ci++)
+			if (plan.classes[ci].cls >= SA_PK_CLASS0)
+				order.push_back((int)ci);
+		std::sort(order.begin(), order.end(), [&](int x, int y) { return plan.classes[(size_t)x].cls > plan.classes[(size_t)y].cls; });
+		for (int ci : order) {
+			const auto &cl = plan.classes[(size_t)ci];
+			const int g = cl.cls >= SA_PK16_CLASS0 ? 16 : 8;
+			const int k = cl.cls - (g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
+			const int klo = sa_pk_bundle_klo(g, k);
+			const int f16 = g == 8 || k <= ctx->pk16_f16_kmax ? 1 : 0;
+			sa_ctx::Plan::PkLaunch *b = nullptr;
+			for (auto &x : plan.pk_launches)
+				if (x.g == g && x.klo == klo && x.f16 == f16)
+					b = &x;
+			if (!b) {
+				plan.pk_launches.emplace_back();
+				b = &plan.pk_launches.back();
+				b->g = g, b->klo = klo, b->f16 = f16, b->kmax = k;
+			}
+			b->kmax = std::max(b->kmax, k);
+			b->cls.push_back(ci);
+		}
+		for (auto &b : plan.pk_launches) {
+			std::vector<SaPkClassArgs> args((size_t)nranks * b.cls.size());
+			b.nlocal.assign((size_t)nranks, 0);
+			b.pairs.assign((size_t)nranks, 0);
+			b.cells.assign((size_t)nranks, 0);
+			for (int r = 0; r < nranks && ok; r++) {
+				int32_t ubase = 0;
+				for (size_t x = 0; x < b.cls.size(); x++) {
+					const auto &cl = plan.classes[(size_t)b.cls[x]];
+					const int k = cl.cls - (b.g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
+					SaPkClassArgs &a = args[(size_t)r * b.cls.size() + x];
+					a.jlist = cl.d_jlist;
+					a.tprefix = cl.d_tprefix;
+					a.tlist = world >= 1 ? cl.d_tlist + cl.rank_first[(size_t)r] : nullptr;
+					a.dense_off = world >= 1 ? cl.d_doff : nullptr;
+					a.ncols = cl.ncols;
+					a.npart = cl.npart;
+					a.k = k;
+					a.delta = pk_delta(ctx, b.g, k);
+					a.pk_base = pk_base(ctx, b.g, k);
+					a.ubase = ubase;
+					const int64_t un = (int64_t)ubase + (world >= 1 ? cl.rank_first[(size_t)r + 1] - cl.rank_first[(size_t)r] : cl.ntiles);
+					if (un > INT32_MAX) {
+						sa_set_error("packed range too large for one launch; split it into smaller ranges");
+						ok = false;
+						break;
+					}
+					ubase = (int32_t)un;
+					b.pairs[(size_t)r] += world >= 1 ? cl.rank_pairs[(size_t)r] : cl.pairs;
+					b.cells[(size_t)r] += world >= 1 ? cl.rank_cells[(size_t)r] : cl.cells;
+				}
+				b.nlocal[(size_t)r] = ubase;
+			}
+			if (ok) {
+				SA_HIP_CHECK(hipMalloc(&b.d_args, sizeof(SaPkClassArgs) * args.size()), ok = false);
+			}
+			if (ok) {
+				SA_HIP_CHECK(hipMemcpy(b.d_args, args.data(), sizeof(SaPkClassArgs) * args.size(), hipMemcpyHostToDevice), ok = false);
+			}
+			if (!ok)
+				break;
+		}
+	}
 	if (!ok) {
 		plan_free(plan);
 		return false;
@@ -938,7 +1227,9 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count)
 
 static const char *const METHOD_TAG[] = { "nw", "ga", "sw" };
 
-static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16);
+/* share: world >= 1 runs the tiles of `rank` only and stores them densely (sa_ctx_align_share); 0: the whole range */
+static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16,
+			    int world = 0, int rank = 0);
 
 extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream)
 {
@@ -983,31 +1274,84 @@ extern "C" int sa_hip_widen16(const int16_t *d_src, int32_t *d_dst, int64_t coun
 	return 0;
 }
 
+/* ---- tile-interleaved sharding: one process per GPU, dense shares, all-gather, widen-and-place ---- */
+static bool share_args_ok(sa_ctx *ctx, int64_t start, int64_t count, int world, const char *who)
+{
+	if (!ctx || start < 0 || count <= 0 || start + count > ctx->pairs || world < 1 || world > 1024) {
+		sa_set_error("%s: bad range [%lld,+%lld) of %lld pairs or world %d", who, (long long)start, (long long)count,
+			     ctx ? (long long)ctx->pairs : -1LL, world);
+		return false;
+	}
+	return true;
+}
+
+extern "C" int64_t sa_ctx_share_elems(sa_ctx *ctx, int64_t start, int64_t count, int world)
+{
+	if (!share_args_ok(ctx, start, count, world, "sa_ctx_share_elems"))
+		return -1;
+	SA_HIP_CHECK(hipSetDevice(ctx->device), return -1);
+	if (!plan_build(ctx, start, count, world))
+		return -1;
+	return ctx->plan->share_elems;
+}
+
+extern "C" int sa_ctx_align_share(sa_ctx *ctx, int64_t start, int64_t count, int world, int rank, void *d_share, int elem16,
+				   void *stream)
+{
+	if (!share_args_ok(ctx, start, count, world, "sa_ctx_align_share"))
+		return 1;
+	if (rank < 0 || rank >= world || !d_share) {
+		sa_set_error("sa_ctx_align_share: rank %d of %d, share buffer %p", rank, world, d_share);
+		return 1;
+	}
+	if (elem16 && !sa_ctx_scores_fit16(ctx)) {
+		sa_set_error("sa_ctx_align_share: scores of this store and scoring are not provably within int16");
+		return 1;
+	}
+	return align_range_impl(ctx, start, count, static_cast<int32_t *>(d_share), stream, elem16 != 0, world, rank);
+}
+
+extern "C" int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, int world, const void *d_shares, int elem16,
+				    int32_t *d_packed, void *stream)
+{
+	if (!share_args_ok(ctx, start, count, world, "sa_ctx_place_shares"))
+		return 1;
+	if (!d_shares || !d_packed) {
+		sa_set_error("sa_ctx_place_shares: null buffer");
+		return 1;
+	}
+	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
+	if (!plan_build(ctx, start, count, world))
+		return 1;
+	SA_HIP_CHECK(sa_launch_place(ctx->plan->d_segs, ctx->plan->nsegs, d_shares, elem16, d_packed, (hipStream_t)stream), return 1);
+	return 0;
+}
+
 /* Arranged row streams of one packed launch of the current plan (builds the copies it needs on first use).  Scores
  * stored straight into host memory must leave in row order: there a block is one tile; in device memory a block may
  * span several tiles (their stores scatter inside it). */
-static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, SaSysArgs &a)
+static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool host_out, SaSysArgs &a)
 {
 	if (ctx->env_no_sort)
 		return true;
 	const int ng = 64 / pk_g;
-	const int32_t rows = SA_PK_WPB * ng * ctx->plan->chunk_pk;
+	const int32_t rows = SA_PK_WPB * ng * chunk_pk;
 	int nl = 0;
 	for (int l = 0; l < SA_PK_SORT_LEVELS; l++) {
 		const int32_t block = SA_PK_SORT_ROWS >> l;
 		/* (a tile of SA_PK_ROWS_OWN_BLOCK rows has enough equal lengths of its own, and storing in row order keeps
 		 * the HBM write traffic at the algorithmic 4 bytes per pair) */
-		if (ctx->out_is_host || rows >= SA_PK_ROWS_OWN_BLOCK || block <= rows || block % rows != 0)
+		if (host_out || rows >= SA_PK_ROWS_OWN_BLOCK || block <= rows || block % rows != 0)
 			continue;
 		const sa_ctx::Arranged *ar = nullptr;
-		if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, block, &ar))
+		if (!arranged_store(ctx, ng, chunk_pk, block, &ar))
 			return false;
 		if (ar)
 			a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
 	}
 	if (nl < SA_PK_SORT_LEVELS) { /* the tile itself as a block: its scores leave in row order */
 		const sa_ctx::Arranged *ar = nullptr;
-		if (!arranged_store(ctx, ng, ctx->plan->chunk_pk, rows, &ar))
+		if (!arranged_store(ctx, ng, chunk_pk, rows, &ar))
 			return false;
 		if (ar)
 			a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
@@ -1031,7 +1375,7 @@ static bool prepare_range(sa_ctx *ctx, int64_t start, int64_t count, bool host_o
 		if (cl.cls < SA_PK_CLASS0)
 			continue;
 		SaSysArgs a{};
-		ok = pk_arranged_levels(ctx, cl.cls >= SA_PK16_CLASS0 ? 16 : 8, a);
+		ok = pk_arranged_levels(ctx, cl.cls >= SA_PK16_CLASS0 ? 16 : 8, ctx->plan->chunk_pk, host_out, a);
 		if (!ok)
 			break;
 	}
@@ -1039,7 +1383,8 @@ static bool prepare_range(sa_ctx *ctx, int64_t start, int64_t count, bool host_o
 	return ok;
 }
 
-static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16)
+static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16,
+			    int world, int rank)
 {
 	if (!ctx || start < 0 || count < 0 || start + count > ctx->pairs || (!d_scores && count)) {
 		sa_set_error("sa_ctx_align_range: bad range [%lld,+%lld) of %lld pairs", (long long)start,
@@ -1050,8 +1395,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		return 0;
 	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
 	hipStream_t s = (hipStream_t)stream;
-	if (!plan_build(ctx, start, count))
+	if (!plan_build(ctx, start, count, world))
 		return 1;
+	const bool share = world >= 1;
 
 	auto timed_begin = [&](hipEvent_t &e0, hipEvent_t &e1) -> bool {
 		if (!ctx->timing)
@@ -1069,9 +1415,26 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		return true;
 	};
 
-	/* systolic streaming kernels: one persistent launch per column-length class; with several classes the
-	 * launches go to side streams forked from / joined back into the caller's stream so they run concurrently */
-	const bool fan_out = ctx->plan->classes.size() > 1 && !ctx->env_serial_classes;
+	/* Systolic streaming kernels.  Packed classes: one persistent launch per BUNDLE (normally one for the whole range).
+	 * s32 classes: one persistent launch per class.  A single launch goes to the caller's stream; several go to side
+	 * streams forked from / joined back into it so that they run concurrently. */
+	const int rk = share ? rank : 0;
+	struct Item {
+		int bundle, cls; /* index into plan->pk_launches, or into plan->classes (s32 classes) */
+	};
+	std::vector<Item> items;
+	for (size_t bi = 0; bi < ctx->plan->pk_launches.size(); bi++)
+		if (ctx->plan->pk_launches[bi].nlocal[(size_t)rk] > 0)
+			items.push_back({ (int)bi, -1 });
+	for (size_t ci = 0; ci < ctx->plan->classes.size(); ci++) {
+		const auto &cl = ctx->plan->classes[ci];
+		if (cl.cls >= SA_PK_CLASS0)
+			continue;
+		if (share && cl.rank_first[(size_t)rank + 1] == cl.rank_first[(size_t)rank])
+			continue;
+		items.push_back({ -1, (int)ci });
+	}
+	const bool fan_out = items.size() > 1 && !ctx->env_serial_classes;
 	const size_t slot = (size_t)(ctx->call_no++ % sa_ctx::COUNTER_SLOTS);
 	unsigned *const counters = ctx->d_counters + slot * sa_ctx::COUNTERS_PER_SLOT;
 	if (ctx->slot_done[slot]) { /* 256 calls ago, possibly on another stream: normally long complete */
@@ -1079,123 +1442,136 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 	} else {
 		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->slot_done[slot], hipEventDisableTiming), return 1);
 	}
-	if (!ctx->plan->classes.empty()) {
-		SA_HIP_CHECK(hipMemsetAsync(counters, 0, sizeof(unsigned) * sa_ctx::COUNTERS_PER_SLOT, s), return 1);
-	}
+	/* (the counters are zero: set so once at context creation, and every launch's last workgroup puts its own back) */
 	if (fan_out) {
 		SA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s), return 1);
 	}
 	hipStream_t caller = s;
 	int launch_no = 0;
-	for (const auto &cl : ctx->plan->classes) {
+	for (const Item &it : items) {
 		const int side_k = launch_no++ % sa_ctx::NSIDE;
 		if (fan_out) {
 			s = ctx->side[side_k];
 			SA_HIP_CHECK(hipStreamWaitEvent(s, ctx->fork_ev, 0), return 1);
 		}
-		const bool is_pk = cl.cls >= SA_PK_CLASS0;
-		const int pk_g = cl.cls >= SA_PK16_CLASS0 ? 16 : 8;
-		const int pk_k = cl.cls - (pk_g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
-		const bool is_long = cl.cls == SA_SYS_CLASS_LONG;
-		const int64_t W = is_pk ? pk_g * pk_k : is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
-					  : SA_SYS_CLASSES[cl.cls].G * SA_SYS_CLASSES[cl.cls].K;
+		const bool is_pk = it.bundle >= 0;
+		const sa_ctx::Plan::PkLaunch *pb = is_pk ? &ctx->plan->pk_launches[(size_t)it.bundle] : nullptr;
+		const sa_ctx::ClassLaunch *clp = is_pk ? nullptr : &ctx->plan->classes[(size_t)it.cls];
+		const int cls = is_pk ? -1 : clp->cls;
+		const bool is_long = cls == SA_SYS_CLASS_LONG;
 		SaSysArgs a{};
 		a.codes = ctx->d_codes;
 		a.off = ctx->d_off;
 		a.sub8 = ctx->d_sub8;
-		a.jlist = cl.d_jlist;
-		a.tprefix = cl.d_tprefix;
-		a.npart = cl.npart;
-		a.ncols = cl.ncols;
 		a.num = ctx->num;
 		a.start = start;
 		a.end = start + count;
 		a.out = d_scores;
 		a.out16 = out16 ? 1 : 0;
-		a.pconst = ctx->sys_pconst;
-		a.q = ctx->sys_q;
 		a.gap_g = ctx->sc.gap_pen;
 		a.gap_o = ctx->sc.gap_opn;
 		a.gap_e = ctx->sc.gap_ext;
-		a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
+		int32_t ntiles_here;
+		int64_t pairs_here, cells_here;
+		char name[96];
 		if (is_pk) {
 			a.pconst = ctx->pk_pconst;
 			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
-			a.delta = pk_delta(ctx, pk_g, pk_k);
-			a.pk_base = pk_base(ctx, pk_g, pk_k);
-			a.out_nt = ctx->out_is_host ? 1 : 0;
-			a.pk_f16 = pk_g == 8 || pk_k <= ctx->pk16_f16_kmax ? 1 : 0;
-			if (!pk_arranged_levels(ctx, pk_g, a))
+			a.out_nt = ctx->out_is_host && !share ? 1 : 0;
+			a.pk_f16 = pb->f16;
+			if (!pk_arranged_levels(ctx, pb->g, ctx->plan->chunk_pk, ctx->out_is_host && !share, a))
 				return 1;
-		}
-		a.counter = counters + cl.cls;
-		a.chunk = is_pk ? ctx->plan->chunk_pk : is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
-		if (is_long) {
-			/* scratch: two lines (V and X) of a wave's longest possible row stream, for every wave of as many
-			 * workgroups as fit a 4 GiB budget */
-			if (!ctx->d_long_scratch) {
-				ctx->long_stride = 2 * (16 * ((int64_t)ctx->max_len + 1) + 64);
-				const int64_t budget_ints = ((int64_t)4 << 30) / 4;
-				const int64_t wpb = SA_SYS_WPB(64, true); /* one pair of lines per wave */
-				ctx->long_wgs = (int)std::max<int64_t>(16, std::min<int64_t>(ctx->persistent_wgs / 4, budget_ints / (ctx->long_stride * wpb)));
-				SA_HIP_CHECK(hipMalloc(&ctx->d_long_scratch, sizeof(int32_t) * (size_t)(ctx->long_stride * ctx->long_wgs * wpb)), return 1);
+			a.chunk = ctx->plan->chunk_pk;
+			a.pkc = pb->d_args + (size_t)rk * pb->cls.size();
+			a.npkc = (int32_t)pb->cls.size();
+			a.nlocal = ntiles_here = pb->nlocal[(size_t)rk];
+			pairs_here = pb->pairs[(size_t)rk];
+			cells_here = pb->cells[(size_t)rk];
+			a.counter = counters + 2 * (SA_PK_CLASS0 + it.bundle);
+			const int klo_seen = ctx->plan->classes[(size_t)pb->cls.back()].cls - (pb->g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
+			snprintf(name, sizeof(name), "sa_k_systolic_pk_bundle<%s,G%d,K%d-%d%s>", METHOD_TAG[ctx->sc.method], pb->g, klo_seen,
+				 pb->kmax, pb->f16 ? "" : ",u16");
+		} else {
+			const auto &cl = *clp;
+			const int64_t W = is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
+						  : SA_SYS_CLASSES[cls].G * SA_SYS_CLASSES[cls].K;
+			a.jlist = cl.d_jlist;
+			a.tprefix = cl.d_tprefix;
+			a.npart = cl.npart;
+			a.ncols = cl.ncols;
+			a.pconst = ctx->sys_pconst;
+			a.q = ctx->sys_q;
+			a.delta = (int32_t)(ctx->sys_gain * W + ctx->sys_slack);
+			a.counter = counters + 2 * cls;
+			a.chunk = is_long ? std::min(ctx->plan->chunk, 16) : ctx->plan->chunk;
+			ntiles_here = cl.ntiles;
+			pairs_here = cl.pairs;
+			cells_here = cl.cells;
+			if (share) {
+				a.tlist = cl.d_tlist + cl.rank_first[(size_t)rank];
+				a.nlocal = ntiles_here = cl.rank_first[(size_t)rank + 1] - cl.rank_first[(size_t)rank];
+				a.dense_off = cl.d_doff;
+				pairs_here = cl.rank_pairs[(size_t)rank];
+				cells_here = cl.rank_cells[(size_t)rank];
 			}
-			a.long_scratch = ctx->d_long_scratch;
-			a.long_stride = ctx->long_stride;
+			if (is_long) {
+				/* scratch: two lines (V and X) of a wave's longest possible row stream, for every wave of as many
+				 * workgroups as fit a 4 GiB budget */
+				if (!ctx->d_long_scratch) {
+					ctx->long_stride = 2 * (16 * ((int64_t)ctx->max_len + 1) + 64);
+					const int64_t budget_ints = ((int64_t)4 << 30) / 4;
+					const int64_t wpb = SA_SYS_WPB(64, true); /* one pair of lines per wave */
+					ctx->long_wgs = (int)std::max<int64_t>(16, std::min<int64_t>(ctx->persistent_wgs / 4, budget_ints / (ctx->long_stride * wpb)));
+					SA_HIP_CHECK(hipMalloc(&ctx->d_long_scratch, sizeof(int32_t) * (size_t)(ctx->long_stride * ctx->long_wgs * wpb)), return 1);
+				}
+				a.long_scratch = ctx->d_long_scratch;
+				a.long_stride = ctx->long_stride;
+				snprintf(name, sizeof(name), "sa_k_systolic<%s,G64,K16,strips>", METHOD_TAG[ctx->sc.method]);
+			} else {
+				snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
+					 SA_SYS_CLASSES[cls].G, SA_SYS_CLASSES[cls].K);
+			}
 		}
-		char name[64];
-		if (is_pk)
-			snprintf(name, sizeof(name), pk_g == 16 ? "sa_k_systolic_pk16<%s,K%d>" : "sa_k_systolic_pk<%s,K%d>",
-				 METHOD_TAG[ctx->sc.method], pk_k);
-		else if (is_long)
-			snprintf(name, sizeof(name), "sa_k_systolic<%s,G64,K16,strips>", METHOD_TAG[ctx->sc.method]);
-		else
-			snprintf(name, sizeof(name), "sa_k_systolic<%s,G%d,K%d>", METHOD_TAG[ctx->sc.method],
-				 SA_SYS_CLASSES[cl.cls].G, SA_SYS_CLASSES[cl.cls].K);
 		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
 		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
 		unsigned long long *d_stamps = nullptr;
+		const size_t nstamp = is_pk ? 1 : (size_t)clp->ntiles;
 		if (ctx->env_stamps) {
-			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
-			SA_HIP_CHECK(hipMemset(d_stamps, 0, 3 * sizeof(unsigned long long) * (size_t)cl.ntiles), return 1);
+			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * nstamp), return 1);
+			SA_HIP_CHECK(hipMemset(d_stamps, 0, 3 * sizeof(unsigned long long) * nstamp), return 1);
 			a.stamps = d_stamps;
 		}
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
 		const int wgs = (int)std::min<int64_t>(is_pk ? ctx->persistent_wgs / 4 : is_long ? ctx->long_wgs : ctx->persistent_wgs,
-						       cl.ntiles);
+						       ntiles_here);
 		if (is_pk) {
-			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pk_g, pk_k, a, wgs, s), return 1);
+			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pb->g, pb->klo, pb->f16, a, wgs,
+							   (unsigned)sa_pk_lds_bytes(pb->g, pb->kmax), s), return 1);
 		} else {
-			SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cl.cls, a, wgs, s), return 1);
+			SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cls, a, wgs, s), return 1);
 		}
 		if (d_stamps) {
-			std::vector<unsigned long long> h(3 * (size_t)cl.ntiles);
+			std::vector<unsigned long long> h(3 * nstamp);
 			SA_HIP_CHECK(hipStreamSynchronize(s), return 1);
 			SA_HIP_CHECK(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost), return 1);
 			(void)hipFree(d_stamps);
 			if (is_pk) { /* packed kernels: totals in the first triple: wave-steps executed, stream rows (8 per wave-step at best), wave-tiles */
 				fprintf(stderr, "[stamps] %s: %llu wave-tiles, %.0f steps per wave-tile, %.3f executed step slots per stream row (1.0 = no bubbles)\n",
-					name, h[2], (double)h[0] / (double)h[2], (double)h[0] * 8.0 / (double)h[1]);
-				if (!timed_end(name, e0, e1, cl.pairs, cl.cells))
-					return 1;
-				if (fan_out) {
-					SA_HIP_CHECK(hipEventRecord(ctx->join_ev[side_k], s), return 1);
-					SA_HIP_CHECK(hipStreamWaitEvent(caller, ctx->join_ev[side_k], 0), return 1);
+					name, h[2], (double)h[0] / (double)h[2], (double)h[0] * (64 / pb->g) / (double)h[1]);
+			} else {
+				double cyc = 0, rt = 0, steps = 0;
+				for (size_t k = 0; k < nstamp; k++) {
+					cyc += (double)h[3 * k];
+					rt += (double)h[3 * k + 1];
+					steps += (double)h[3 * k + 2];
 				}
-				continue;
+				fprintf(stderr, "[stamps] %s: %zu wave-tiles, %.1f cycles/step per wave, clock %.0f MHz, %.0f steps/tile\n",
+					name, nstamp, cyc / steps, cyc / rt * 100.0, steps / (double)nstamp);
 			}
-			double cyc = 0, rt = 0, steps = 0;
-			for (int32_t k = 0; k < cl.ntiles; k++) {
-				cyc += (double)h[3 * (size_t)k];
-				rt += (double)h[3 * (size_t)k + 1];
-				steps += (double)h[3 * (size_t)k + 2];
-			}
-			fprintf(stderr, "[stamps] %s: %d wave-tiles, %.1f cycles/step per wave, clock %.0f MHz, %.0f steps/tile\n",
-				name, cl.ntiles, cyc / steps, cyc / rt * 100.0, steps / cl.ntiles);
 		}
-		if (!timed_end(name, e0, e1, cl.pairs, cl.cells))
+		if (!timed_end(name, e0, e1, pairs_here, cells_here))
 			return 1;
 		if (fan_out) {
 			SA_HIP_CHECK(hipEventRecord(ctx->join_ev[side_k], s), return 1);
@@ -1206,7 +1582,19 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 	SA_HIP_CHECK(hipEventRecord(ctx->slot_done[slot], s), return 1);
 
 	/* everything the fast path does not cover: pair-per-wave kernels on contiguous packed runs */
-	for (const auto &run : ctx->plan->generic) {
+	/* (share: this rank's pieces of those runs, each at its offset of the dense share) */
+	std::vector<std::pair<int64_t, int64_t>> runs = ctx->plan->generic;
+	std::vector<int64_t> run_out;
+	if (share) {
+		runs.clear();
+		for (const auto &gs : ctx->plan->generic_share[(size_t)rank]) {
+			runs.emplace_back(gs.start, gs.count);
+			run_out.push_back(gs.doff);
+		}
+	}
+	for (size_t ri = 0; ri < runs.size(); ri++) {
+		const auto &run = runs[ri];
+		const int64_t out_at = share ? run_out[ri] : run.first - start;
 		SaGenericArgs a{};
 		a.st.codes = ctx->d_codes;
 		a.st.meta = ctx->d_meta;
@@ -1217,8 +1605,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		a.gap_ext = ctx->sc.gap_ext;
 		a.start = run.first;
 		a.count = run.second;
-		a.out = out16 ? reinterpret_cast<int32_t *>(reinterpret_cast<int16_t *>(d_scores) + (run.first - start))
-			      : d_scores + (run.first - start);
+		a.out = out16 ? reinterpret_cast<int32_t *>(reinterpret_cast<int16_t *>(d_scores) + out_at) : d_scores + out_at;
 		a.out16 = out16 ? 1 : 0;
 		a.scratch = ctx->d_scratch;
 		a.scratch_stride = ctx->scratch_stride;

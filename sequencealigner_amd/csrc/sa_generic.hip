@@ -288,7 +288,36 @@ hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t n
 	return hipGetLastError();
 }
 
-/* see sa_warm_kernels: the pair-per-wave, expand and widen kernels live in this translation unit */
+/* Widen-and-place (tile-interleaved sharding, sa_ctx_place_shares): the gathered dense shares -- every rank's scores in
+ * tile order, int16 or s32 -- into the reference's packed order.  One workgroup per run of a tile (SaPlaceSeg): reads are
+ * contiguous, writes land inside one arranged block of the column (<= 2048 rows = an 8 KB window the L2 merges), in row
+ * order where the tile streamed in store order. */
+template <typename T>
+__global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__ segs, const T *__restrict__ shares,
+						   int32_t *__restrict__ packed)
+{
+	const SaPlaceSeg sg = segs[blockIdx.x];
+	const T *src = shares + sg.src;
+	int32_t *dst = packed + sg.dst;
+	for (int32_t p = threadIdx.x; p < sg.count; p += 256) {
+		const int32_t r = sg.rowmap ? sg.rowmap[sg.pos0 + p] : sg.pos0 + p;
+		if (r >= sg.ia && r < sg.ib)
+			dst[r] = (int32_t)src[p];
+	}
+}
+
+hipError_t sa_launch_place(const SaPlaceSeg *segs, int32_t nsegs, const void *shares, int elem16, int32_t *packed, hipStream_t s)
+{
+	if (nsegs <= 0)
+		return hipSuccess;
+	if (elem16)
+		hipLaunchKernelGGL(sa_k_place<int16_t>, dim3((unsigned)nsegs), dim3(256), 0, s, segs, static_cast<const int16_t *>(shares), packed);
+	else
+		hipLaunchKernelGGL(sa_k_place<int32_t>, dim3((unsigned)nsegs), dim3(256), 0, s, segs, static_cast<const int32_t *>(shares), packed);
+	return hipGetLastError();
+}
+
+/* see sa_warm_kernels: the pair-per-wave, expand, widen and place kernels live in this translation unit */
 hipError_t sa_warm_generic(void)
 {
 	hipFuncAttributes attr;

@@ -100,6 +100,28 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 + SA_PK_KMAX + 1,
 	     SA_PLAN_NCLASSES = SA_PK16_CLASS0 + SA_PK16_KMAX + 1 };
 
+/* The packed kernels are launched as BUNDLES: one persistent kernel (sa_k_systolic_pk_bundle<METHOD, G, KLO, F16>) walks
+ * the tiles of up to SA_PK_BUNDLE consecutive K classes, class after class -- one launch on the caller's stream, one tail
+ * for the whole range instead of one per class, and no cross-stream fork / join (six class launches on side streams ran
+ * as two rounds of three on the runtime's hardware queues and cost ~70 us of events and barriers per range:
+ * profiles/r03a_*).  8-lane groups: KLO = 1, 9, 17; 16-lane groups: KLO = 13, 21, 29, 37.  The registers of a bundle are
+ * those of its largest K (K <= 16: <= 127 VGPRs for every method, four waves per SIMD as before). */
+#define SA_PK_BUNDLE 8
+struct SaPkClassArgs { /* one class of a bundle launch, in device memory (share plans: one array per rank) */
+	const int32_t *jlist;     /* columns (ascending) of the class                                        */
+	const int32_t *tprefix;   /* full tiles before each column pair, then the pairs of the partial tiles */
+	const int32_t *tlist;     /* share plans: this rank's tiles of the class; nullptr: all of them       */
+	const int64_t *dense_off; /* share plans: element offset of tile t in its owner's dense share        */
+	int32_t ncols, npart, k;
+	int32_t delta, pk_base;
+	int32_t ubase;            /* launch-tile index of the class's first tile (classes are walked in order) */
+};
+/* LDS of a packed workgroup: scores leaving the pipeline, token rings, then the profile of the column pair (the only
+ * part that depends on K): a launch asks for the bytes of its largest K as dynamic LDS */
+__host__ __device__ constexpr int sa_pk_lds_fixed(int g) { return 1664 * (64 / g); }
+__host__ __device__ constexpr int sa_pk_lds_bytes(int g, int k) { return sa_pk_lds_fixed(g) + SA_CODE_ROWS * ((k + 3) / 4) * 256; }
+inline int sa_pk_bundle_klo(int g, int k) { return g == 8 ? 1 + (k - 1) / SA_PK_BUNDLE * SA_PK_BUNDLE : SA_PK_K16_MIN + (k - SA_PK_K16_MIN) / SA_PK_BUNDLE * SA_PK_BUNDLE; }
+
 struct SaSysArgs {
 	const uint8_t *codes;    /* encoded store, tight layout: sequence k at off[k], terminator after it */
 	const int32_t *off;      /* num+1 offsets; len_k = off[k+1]-off[k]-1                              */
@@ -129,15 +151,60 @@ struct SaSysArgs {
 	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
 	int32_t out_nt;          /* packed kernels: out is host memory, store non-temporally                        */
 	int32_t pk_f16;          /* packed kernels: the class's values fit SA_PK_F16_MAX (three-way f16 maxima)     */
-	unsigned *counter;       /* next unclaimed wave-tile of this launch (zeroed by the host)            */
+	/* tile-interleaved sharding (sa_ctx_align_share): this launch runs the tiles tlist[0..nlocal) of the class's tile
+	 * list and stores the scores of tile t densely at out[dense_off[t] ...] in tile order -- packed kernels: two runs of
+	 * SA_SHARE_PAD(rows) elements (column A, column B) in POSITION order of the row stream; s32 kernels: the tile's rows.
+	 * tlist == nullptr: every tile of the list; dense_off == nullptr: packed order, out[p - start]. */
+	const int32_t *tlist;
+	const int64_t *dense_off;
+	int32_t nlocal;
+	const SaPkClassArgs *pkc; /* packed bundle launch: its classes in walking order; nlocal = tiles of the whole launch */
+	int32_t npkc;
+	unsigned *counter;       /* [0] next unclaimed tile of this launch, [1] workgroups that have left; both zero before
+	                          * the launch and put back to zero by its last workgroup                           */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
 };
 
+/* rows of a tile's run in a dense share, padded so that every run starts 16-byte aligned in int16 and s32 alike */
+#define SA_SHARE_PAD(rows) (((rows) + 7) & ~7)
+
+/* Which arranged copy of the row store a packed tile streams (kernel and host must agree: the host builds the
+ * placement of a dense share from it).  lvrows[l] = rows per block of level l (0: level not offered), largest first;
+ * ra, rb = row range of the column pair, i_begin = the tile's first position, tile_rows = rows of a FULL tile.
+ * A tile takes the largest offered block that lies inside [ra, rb) around it; -1: store order. */
+__host__ __device__ inline int sa_pk_pick_level(const int32_t *lvrows, int32_t ra, int32_t rb, int32_t i_begin, int32_t tile_rows)
+{
+	int pick = -1;
+	if (ra % tile_rows != 0)
+		return pick;
+	for (int l = SA_PK_SORT_LEVELS - 1; l >= 0; l--) { /* smallest first: a larger fitting block overrides */
+		const int32_t sr = lvrows[l];
+		if (sr <= 0)
+			continue;
+		const int32_t blk0 = i_begin / sr * sr;
+		if (blk0 >= ra && blk0 + sr <= rb)
+			pick = l;
+	}
+	return pick;
+}
+
+/* one run of a dense share and where it goes in the packed matrix (sa_k_place): element p of the run is the score of
+ * row r = rowmap ? rowmap[pos0 + p] : pos0 + p, stored at packed[dst + r] if ia <= r < ib */
+struct SaPlaceSeg {
+	int64_t src;           /* element offset in the gathered shares (rank-major)                 */
+	int64_t dst;           /* tri(j) - start of the placed range; generic runs: run start - start */
+	const int32_t *rowmap; /* arranged tiles: position -> row                                     */
+	int32_t count, pos0, ia, ib;
+};
+hipError_t sa_launch_place(const SaPlaceSeg *segs, int32_t nsegs, const void *shares, int elem16, int32_t *packed, hipStream_t s);
+
 /* `workgroups` persistent workgroups pull the launch's wave-tiles from a.counter */
 hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workgroups, hipStream_t s);
-/* packed-u16 kernels: class K of SA_PK_K_LIST; jlist holds the columns, tprefix the tiles before each column PAIR */
-hipError_t sa_launch_systolic_pk(int method, int g, int k, const SaSysArgs &a, int workgroups, hipStream_t s);
+/* packed-u16 kernels: the bundle of classes a.pkc[0 .. a.npkc) (all of lane-group width g, K in [klo, klo + SA_PK_BUNDLE),
+ * all three-way (f16) or not); lds_bytes = sa_pk_lds_bytes(g, largest K of the launch) */
+hipError_t sa_launch_systolic_pk(int method, int g, int klo, int f16, const SaSysArgs &a, int workgroups, unsigned lds_bytes,
+				 hipStream_t s);
 /* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */
 enum : int { SA_WARM_S32 = 1, SA_WARM_PK8 = 2, SA_WARM_PK16 = 4 }; /* kernel families (one code object each per method) */
 hipError_t sa_warm_kernels(int method, int families);

@@ -20,8 +20,8 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 }
 
 #define SA_PK_DECL(M)                                                                                  \
-	hipError_t sa_launch_systolic_pk_##M(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s);   \
-	hipError_t sa_launch_systolic_pk16_##M(int g, int k, const SaSysArgs &a, int tiles, hipStream_t s); \
+	hipError_t sa_launch_systolic_pk_##M(int g, int klo, int f16, const SaSysArgs &a, int wgs, unsigned lds, hipStream_t s);   \
+	hipError_t sa_launch_systolic_pk16_##M(int g, int klo, int f16, const SaSysArgs &a, int wgs, unsigned lds, hipStream_t s); \
 	hipError_t sa_warm_systolic_pk_##M(void);                                                           \
 	hipError_t sa_warm_systolic_pk16_##M(void);                                                         \
 	hipError_t sa_warm_systolic_##M(void);
@@ -31,15 +31,15 @@ SA_PK_DECL(sw)
 #undef SA_PK_DECL
 hipError_t sa_warm_generic(void);
 
-hipError_t sa_launch_systolic_pk(int method, int g, int k, const SaSysArgs &a, int tiles, hipStream_t s)
+hipError_t sa_launch_systolic_pk(int method, int g, int klo, int f16, const SaSysArgs &a, int wgs, unsigned lds, hipStream_t s)
 {
 	switch (method) {
 	case SA_METHOD_NW:
-		return g == 8 ? sa_launch_systolic_pk_nw(g, k, a, tiles, s) : sa_launch_systolic_pk16_nw(g, k, a, tiles, s);
+		return g == 8 ? sa_launch_systolic_pk_nw(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_nw(g, klo, f16, a, wgs, lds, s);
 	case SA_METHOD_GA:
-		return g == 8 ? sa_launch_systolic_pk_ga(g, k, a, tiles, s) : sa_launch_systolic_pk16_ga(g, k, a, tiles, s);
+		return g == 8 ? sa_launch_systolic_pk_ga(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_ga(g, klo, f16, a, wgs, lds, s);
 	case SA_METHOD_SW:
-		return g == 8 ? sa_launch_systolic_pk_sw(g, k, a, tiles, s) : sa_launch_systolic_pk16_sw(g, k, a, tiles, s);
+		return g == 8 ? sa_launch_systolic_pk_sw(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_sw(g, klo, f16, a, wgs, lds, s);
 	default:
 		return hipErrorInvalidValue;
 	}

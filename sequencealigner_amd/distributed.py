@@ -1,13 +1,18 @@
-"""Sharding of the packed pair index across ranks (one process per GPU) -- SURVEY.md §8(e).
+"""Sharding of the pair space across ranks (one process per GPU) -- SURVEY.md §8(e).
 
-The units (pairs) are independent, the inputs (<= a few MB) are replicated on every GPU, so each rank
-scores one contiguous range of the packed index -- the reference's own batch abstraction
-`kernel(scores, start, batch)` (src/bio/align.h:48) -- and a single all-gather (RCCL over xGMI when the
-process group is "nccl") assembles the packed vector on every rank.  Equal-count ranges are padded to a
-common length so the gather lands in place in one buffer of world*per elements.
+The units (pairs) are independent and the inputs (<= a few MB) are replicated on every GPU; only the output is
+sharded, and one all-gather per super-chunk (RCCL over xGMI when the process group is "nccl") assembles it.
 
-`ChunkedGather` is the index arithmetic (no torch); `GatherStep` is the overlapped multi-stream step that
-bench.py times and tests/test_gpu_gather_step.py checks on the GPU."""
+`TiledGatherStep` (what bench.py times at N > 1) -- north_star's "pair space tiled across the GPUs": the launch plan
+of a super-chunk (its largest-first list of workgroup-tiles) is the same on every rank, the tiles are dealt over the
+ranks by DP work (sa_ctx_align_share), every rank stores its tiles densely in tile order, the all-gather moves those
+dense shares, and sa_ctx_place_shares widens and places them into the reference's packed order on every GPU.  Every
+rank keeps full-size tiles and whole arranged row blocks, whatever the world size.
+
+`GatherStep` / `ChunkedGather` -- the contiguous-range variant (the reference's own batch abstraction
+`kernel(scores, start, batch)`, src/bio/align.h:48): rank r scores one contiguous range per super-chunk, the gather
+lands in place in packed order.  Kept for A/B runs (`SA_BENCH_PARTITION=range`); at 8 ranks its short ranges force
+quarter-size tiles (85-88 % of the ideal share on cfg 2)."""
 from __future__ import annotations
 
 
@@ -133,3 +138,166 @@ class GatherStep:
         fin = torch.cuda.Event()
         fin.record(self.deliver)
         self.main.wait_event(fin)
+
+
+# ---- tile-interleaved sharding -------------------------------------------------------------------------------
+
+def tri(j: int) -> int:
+    return j * (j - 1) // 2
+
+
+def column_chunks(n: int, chunks: int, ratio: float = 3.0) -> list[tuple[int, int]]:
+    """Column-aligned super-chunks [(start, count)] of the packed index of n sequences, GEOMETRIC in pairs (each
+    `ratio` times smaller than the one before): the all-gather + place + host copy of a super-chunk hides behind the
+    kernels of the next one, and what nothing hides -- the tail of the last one -- is small."""
+    pairs = tri(n)
+    chunks = max(1, min(int(chunks), n - 1))
+    w = [ratio ** (chunks - 1 - c) for c in range(chunks)]
+    cuts, acc = [1], 0.0  # column 0 holds no pair; cuts are column indices
+    for c in range(chunks - 1):
+        acc += w[c] / sum(w)
+        j = int(round((1 + (1 + 8 * acc * pairs) ** 0.5) / 2))  # tri(j) ~ acc * pairs
+        cuts.append(min(n - 1, max(cuts[-1] + 1, j)))
+    cuts.append(n)
+    out = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            out.append((tri(a), tri(b) - tri(a)))
+    return out
+
+
+def host_piece(start: int, count: int, world: int, rank: int) -> tuple[int, int]:
+    """packed range [lo, hi) of a super-chunk that `rank` copies to ITS host buffer (every rank drives its own PCIe link;
+    on one node the pieces make up the matrix)"""
+    per = (count + world - 1) // world
+    lo = min(count, rank * per)
+    return start + lo, start + min(count, lo + per)
+
+
+class HipShares:
+    """The device side of TiledGatherStep: sa_ctx_share_elems / sa_ctx_align_share / sa_ctx_place_shares on torch
+    tensors and streams."""
+
+    device = "cuda"
+
+    def __init__(self, ctx, use16: bool):
+        import torch
+        self.torch, self.ctx, self.use16 = torch, ctx, bool(use16)
+        self.dtype = torch.int16 if use16 else torch.int32
+
+    def share_elems(self, start, count, world):
+        return self.ctx.share_elems(start, count, world)
+
+    def align_share(self, start, count, world, rank, share, stream):
+        self.ctx.align_share(start, count, world, rank, share.data_ptr(), self.use16, stream.cuda_stream)
+
+    def place(self, start, count, world, shares, packed_range, stream):
+        self.ctx.place_shares(start, count, world, shares.data_ptr(), self.use16, packed_range.data_ptr(), stream.cuda_stream)
+
+
+class _Inline:
+    """stream / event stand-ins for a CPU backend (tests/test_multirank_gloo.py): everything runs in program order"""
+
+    def wait_event(self, ev):
+        pass
+
+    def record(self, stream=None):
+        pass
+
+
+class TiledGatherStep:
+    """One whole-job step on `world` ranks with tile-interleaved shares (see the module docstring).
+
+    Per super-chunk c (geometric column ranges; streams of this rank, nothing below synchronises the host):
+      compute[c]  sa_ctx_align_share: the kernels of MY tiles of super-chunk c      -> my dense share (int16 or s32)
+      comm        all_gather_into_tensor(shares[c], my share)                        -> every GPU holds all shares
+      deliver     sa_ctx_place_shares: widen + place into packed[start_c ...];
+                  device->host copy of this rank's 1/world piece of the finished super-chunk into pinned memory
+    The step returns with the main stream waiting for everything: an event on the main stream marks "packed s32
+    vector complete on every GPU AND this rank's piece of it on the host".
+
+    `dist=None` with world > 1 emulates the other ranks on this device (their shares are computed here too, in place of
+    the all-gather): tests and one-GPU rehearsals."""
+
+    def __init__(self, backend, n: int, world: int, rank: int, chunks: int, dist=None, to_host: bool = True):
+        import torch
+
+        self.torch, self.be, self.dist = torch, backend, dist
+        self.world, self.rank = world, rank
+        self.pairs = tri(n)
+        self.ranges = column_chunks(n, chunks)
+        self.chunks = len(self.ranges)
+        cuda = backend.device == "cuda"
+        self.elems = [backend.share_elems(lo, cnt, world) for lo, cnt in self.ranges]
+        self.shares = [torch.zeros(world * e, dtype=backend.dtype, device=backend.device) for e in self.elems]
+        self.packed = torch.zeros(self.pairs, dtype=torch.int32, device=backend.device)
+        self.to_host = bool(to_host)
+        self.pieces = [host_piece(lo, cnt, world, rank) for lo, cnt in self.ranges]
+        self.host_off = [0]
+        for lo, hi in self.pieces:
+            self.host_off.append(self.host_off[-1] + hi - lo)
+        self.host = None
+        if self.to_host:
+            self.host = torch.zeros(max(self.host_off[-1], 1), dtype=torch.int32)
+            if cuda:
+                self.host = self.host.pin_memory()
+        if cuda:
+            self.main = torch.cuda.current_stream()
+            self.compute = [torch.cuda.Stream() for _ in range(self.chunks)]
+            self.comm, self.deliver = torch.cuda.Stream(), torch.cuda.Stream()
+            self._event = torch.cuda.Event
+        else:
+            self.main = _Inline()
+            self.compute = [_Inline() for _ in range(self.chunks)]
+            self.comm, self.deliver = _Inline(), _Inline()
+            self._event = _Inline
+
+    def my_share(self, c: int, r: int | None = None):
+        r = self.rank if r is None else r
+        return self.shares[c][r * self.elems[c]:(r + 1) * self.elems[c]]
+
+    def host_ranges(self):
+        """[(packed_lo, packed_hi, host_offset)] of what this rank delivers"""
+        return [(lo, hi, off) for (lo, hi), off in zip(self.pieces, self.host_off)]
+
+    def __call__(self):
+        torch, dist, be = self.torch, self.dist, self.be
+        cuda = be.device == "cuda"
+        start = self._event()
+        start.record(self.main)
+        for c, (lo, cnt) in enumerate(self.ranges):
+            cs = self.compute[c]
+            cs.wait_event(start)  # ordered after the previous step
+            ranks = [self.rank] if (dist is not None or self.world == 1) else range(self.world)
+            for r in ranks:  # (more than one only when the other ranks are emulated here)
+                be.align_share(lo, cnt, self.world, r, self.my_share(c, r), cs)
+            done = self._event()
+            done.record(cs)
+            gathered = done
+            if dist is not None and self.world > 1:
+                self.comm.wait_event(done)
+                ctxm = torch.cuda.stream(self.comm) if cuda else _null()
+                with ctxm:
+                    # (the process group moves bytes; int16 is not among its dtypes, uint8 is)
+                    dist.all_gather_into_tensor(self.shares[c].view(torch.uint8), self.my_share(c).view(torch.uint8))
+                gathered = self._event()
+                gathered.record(self.comm)
+            self.deliver.wait_event(gathered)
+            be.place(lo, cnt, self.world, self.shares[c], self.packed[lo:lo + cnt], self.deliver)
+            if self.to_host:
+                plo, phi = self.pieces[c]
+                if phi > plo:
+                    ctxm = torch.cuda.stream(self.deliver) if cuda else _null()
+                    with ctxm:
+                        self.host[self.host_off[c]:self.host_off[c] + phi - plo].copy_(self.packed[plo:phi], non_blocking=True)
+        fin = self._event()
+        fin.record(self.deliver)
+        self.main.wait_event(fin)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
