@@ -64,7 +64,9 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2")
     ap.add_argument("--n", "--nseq", dest="n", type=int, default=None, help="override sequence count (parity/debug runs)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration of a bounded sample")
+    ap.add_argument("--cpu-full-seconds", type=float, default=100.0,
+                    help="run the CPU reference over the WHOLE workload (and compare every score) when that is projected to take at most this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-boundary", action="store_true", help="skip the sa_hip_align / CLI end-to-end legs (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs legs (cfg3, cfg4 shape)")
@@ -91,8 +93,14 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(seqs, cfg, target_s: float) -> dict:
-    """Reference CPU path on a bounded prefix of the same workload (pairs/s, all host cores)."""
+def cpu_baseline(seqs, cfg, target_s: float, full_s: float, got=None) -> tuple[dict, dict | None]:
+    """Reference CPU path on the same workload (pairs/s, all host cores) -> (cpu_baseline, parity).
+
+    A calibration run on 600 sequences projects the whole workload; when the projection is within `full_s` seconds the
+    reference runs over the WHOLE workload -- that run is then the baseline measurement -- otherwise over a prefix
+    sized for `target_s` seconds.  Either way the scores it returns are compared, untimed, with the same prefix of the
+    host-delivered matrix `got` (the packed index of the first n sequences is the first n(n-1)/2 elements): `parity`."""
+    import numpy as np
     import sequencealigner_amd as sa
     from tests.oracle_binding import Oracle, RefLib, ref_available
 
@@ -107,13 +115,13 @@ def cpu_baseline(seqs, cfg, target_s: float) -> dict:
             ref = RefLib(cfg["method"], cfg["matrix"], threads=threads, **cfg["gaps"])
             try:
                 t = time.perf_counter()
-                ref.align(store, triangular=True)
-                return time.perf_counter() - t, store
+                scores = ref.align(store, triangular=True)
+                return time.perf_counter() - t, store, scores
             finally:
                 ref.close()
         t = time.perf_counter()
-        oracle.align(store, scoring, triangular=True, threads=threads)
-        return time.perf_counter() - t, store
+        scores = oracle.align(store, scoring, triangular=True, threads=threads)
+        return time.perf_counter() - t, store, scores
 
     use_ref = False
     if ref_available():
@@ -123,17 +131,26 @@ def cpu_baseline(seqs, cfg, target_s: float) -> dict:
         except Exception:
             use_ref = False
     n0 = min(len(seqs), 600)
-    t0, _ = run(n0, use_ref)
+    t0, _, _ = run(n0, use_ref)
     rate = (n0 * (n0 - 1) / 2) / max(t0, 1e-6)
-    n = int(min(len(seqs), max(n0, (2 * rate * target_s) ** 0.5)))
-    t, store = run(n, use_ref)
+    total_pairs = len(seqs) * (len(seqs) - 1) / 2
+    full = total_pairs / rate <= full_s
+    n = len(seqs) if full else int(min(len(seqs), max(n0, (2 * rate * target_s) ** 0.5)))
+    t, store, scores = run(n, use_ref)
     pairs = n * (n - 1) // 2
-    return {
+    base = {
         "value": pairs / t, "unit": "pair-alignments/s", "cores": threads,
         "kind": "reference" if use_ref else "port",
-        "sample": f"first {n} sequences of the workload = {pairs} pairs, {store.cells()} cells, {t:.2f} s",
+        "sample": (f"the whole workload: {n} sequences = {pairs} pairs, {store.cells()} cells, {t:.2f} s" if full else
+                   f"first {n} sequences of the workload = {pairs} pairs, {store.cells()} cells, {t:.2f} s"),
         "gcups": store.cells() / t / 1e9,
     }
+    parity = None
+    if got is not None:
+        mism = int(np.count_nonzero(np.asarray(got[:pairs]) != scores))
+        parity = {"pairs_compared": pairs, "mismatches": mism, "against": "reference" if use_ref else "port",
+                  "whole_workload": bool(full), "compared": "host-delivered packed matrix (sa_ctx_align_host, the timed path) vs the CPU scores"}
+    return base, parity
 
 
 def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_size: bool = True) -> dict:
@@ -149,9 +166,10 @@ def roofline_of(tm: dict, store, steps: int, workload: str, world: int, full_siz
     traffic = None
     for tf in sorted((ROOT / "profiles").glob("*_traffic.json")):
         tj = json.loads(tf.read_text())
+        # (a file that does not say which launch it measured -- sequence count and pairs per launch -- is never quoted)
         if (tj.get("kernel") == tm["kernel"] and tj.get("workload") == workload and world == 1
-                and (tj["n_sequences"] == store.num if "n_sequences" in tj else full_size)
-                and abs(tj.get("pairs_per_launch", k_pairs) - k_pairs) <= 0.02 * k_pairs):
+                and tj.get("n_sequences") == store.num and "pairs_per_launch" in tj
+                and abs(tj["pairs_per_launch"] - k_pairs) <= 0.02 * k_pairs):
             traffic = tj["traffic_bytes_per_launch"]
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "kernel": tm["kernel"], "kernel_avg_ms": avg_ms, "launches": tm["launches"],
@@ -232,7 +250,7 @@ def cli_leg(seqs, cfg) -> dict | None:
                     "setup = context, code-object load, upload, buffers and page-locking (outside the phases as in the reference)"}
 
 
-def extra_config(name: str, n, steps: int, cpu_seconds: float, torch, sa, make_config) -> dict:
+def extra_config(name: str, n, steps: int, cpu_seconds: float, cpu_full_seconds: float, torch, sa, make_config) -> dict:
     """cfg3 / cfg4-shape leg: the same measurement as the headline, a few steps, in this process"""
     seqs, cfg = make_config(name, n)
     store = sa.SequenceStore.from_sequences(seqs)
@@ -240,12 +258,16 @@ def extra_config(name: str, n, steps: int, cpu_seconds: float, torch, sa, make_c
     pairs, cells = store.pairs, store.cells()
     ctx = sa.Context(store, scoring, 0)
     dest = sa.PinnedMatrix(pairs)
+    base = parity = None
     try:
         elapsed, tm = time_host_steps(ctx, dest, steps, 1, torch)
         packed = torch.empty(pairs, dtype=torch.int32, device="cuda")
         el_res, _ = time_resident_steps(ctx, packed, pairs, steps, 1, torch)
         same = bool((torch.from_numpy(dest.array).cuda() == packed).all().item())
         del packed
+        ctx.close()
+        if cpu_seconds > 0:
+            base, parity = cpu_baseline(seqs, cfg, cpu_seconds, cpu_full_seconds, dest.array)
     finally:
         ctx.close()
         dest.close()
@@ -256,7 +278,8 @@ def extra_config(name: str, n, steps: int, cpu_seconds: float, torch, sa, make_c
            "device_resident": {"ms_per_step": el_res / steps * 1e3, "value": pairs * steps / el_res, "gcups": cells * steps / el_res / 1e9},
            "host_result_equals_device_result": same,
            "roofline": roofline_of(tm, store, steps, name, 1, n is None), "valu": valu_of(cfg["method"], cells, sec)}
-    out["cpu_baseline"] = cpu_baseline(seqs, cfg, cpu_seconds) if cpu_seconds > 0 else None
+    out["cpu_baseline"] = base
+    out["parity"] = parity
     return out
 
 
@@ -268,7 +291,7 @@ def main():
     import numpy as np
     import torch
     import sequencealigner_amd as sa
-    from sequencealigner_amd.distributed import GatherStep
+    from sequencealigner_amd.distributed import GatherStep, HipShares, TiledGatherStep
     from tests.synth import CONFIGS, make_config
 
     if args.config not in CONFIGS:
@@ -340,37 +363,49 @@ def main():
             del host
             out["host_boundary"] = {
                 "seconds": e2e, "pairs_per_s": pairs / e2e, "align_phase_seconds": e2e_phase,
+                # the cold call itemised by the library (sa_hip_last_align_breakdown): everything but phase_ms is set-up
+                # the reference keeps outside its bracket too; matrix_alloc_ms = the binding's zero-filled numpy matrix
+                **sa.last_align_breakdown(), "matrix_alloc_and_call_overhead_ms": e2e * 1e3 - sa.last_align_breakdown().get("total_ms", 0.0),
                 "align_phase_pairs_per_s": pairs / e2e_phase if e2e_phase > 0 else None,
                 "note": "one sa_hip_align call on a pageable destination: encode + context + upload + page-locking + loop; "
                         "align_phase = its launch/copy loop only",
                 "cli": cli_leg(seqs, cfg)}
         del packed
+        ctx.close()
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"], out["parity"] = cpu_baseline(seqs, cfg, args.cpu_seconds, args.cpu_full_seconds,
+                                                              dest.array if dest is not None else None)
         if dest is not None:
             dest.close()
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(seqs, cfg, args.cpu_seconds)
-        ctx.close()
         if not args.no_extra and args.config == "cfg2" and args.n is None and not args.device_resident_only:
             cpu_s = 0.0 if args.no_cpu_baseline else max(3.0, args.cpu_seconds / 2)
             extra = {}
             for key, (name, n) in {"cfg3": ("cfg3", None), "cfg4": ("cfg4", CFG4_SHAPE_N)}.items():
-                extra[key] = extra_config(name, n, 3, cpu_s, torch, sa, make_config)
+                extra[key] = extra_config(name, n, 3, cpu_s, args.cpu_full_seconds, torch, sa, make_config)
             out["extra"] = {"configs": extra}
         print(json.dumps(out), flush=True)
         return
 
-    # ---- N > 1 (or the 1-rank RCCL rehearsal): slices + overlapped all-gathers + per-rank host delivery ----
+    # ---- N > 1 (or the 1-rank RCCL rehearsal): tile-interleaved shares + overlapped all-gathers + per-rank host delivery ----
     # exchange format of the all-gather: int16 when every score of this workload provably fits (half the bytes over
-    # xGMI); the gathered vector is widened to the reference's s32 on every GPU inside the timed step
+    # xGMI); the gathered shares are widened to the reference's s32 and placed into packed order on every GPU inside
+    # the timed step
     use16 = ctx.scores_fit16 and not os.environ.get("SA_BENCH_GATHER32")
-    # super-chunks per step: more of them hide more of the all-gather behind the kernels but shorten the kernels'
-    # row streams; the trade depends on the fabric, so (unless --chunks fixes it) it is measured before the warmup,
+    tiled = os.environ.get("SA_BENCH_PARTITION", "tiled") != "range"  # "range": contiguous packed ranges per rank (A/B)
+
+    def make_step(c):
+        if tiled:
+            return TiledGatherStep(HipShares(ctx, use16), store.num, world, rank, c, dist)
+        return GatherStep(ctx, pairs, world, rank, c, dist, use16)
+
+    # super-chunks per step: more of them hide more of the all-gather / place / host copy behind the kernels but add
+    # launches; the trade depends on the fabric, so (unless --chunks fixes it) it is measured before the warmup,
     # untimed, and every rank takes the same decision from the max-over-ranks time
-    candidates = [args.chunks] if args.chunks else [1, 2, 4]
+    candidates = [args.chunks] if args.chunks else ([1, 2, 3] if tiled else [1, 2, 4])
     tuned = {}
     if len(candidates) > 1:
         for c in candidates:
-            trial = GatherStep(ctx, pairs, world, rank, c, dist, use16)
+            trial = make_step(c)
             trial(); trial()
             fence()
             t0 = time.perf_counter()
@@ -382,9 +417,11 @@ def main():
             tuned[c] = float(t.item()) / 4 * 1e3
             del trial
         candidates = [min(tuned, key=tuned.get)]
-    step = GatherStep(ctx, pairs, world, rank, candidates[0], dist, use16)
-    sched = step.sched
-    my_cells = sum(store.cells(lo, hi - lo) for lo, hi in (sched.slice_range(c) for c in range(sched.chunks)))
+    step = make_step(candidates[0])
+    nchunks = step.chunks if tiled else step.sched.chunks
+    my_cells = cells // world  # (tiled: the ranks' shares are balanced by DP work)
+    if not tiled:
+        my_cells = sum(store.cells(lo, hi - lo) for lo, hi in (step.sched.slice_range(c) for c in range(nchunks)))
 
     for _ in range(args.warmup):
         step()
@@ -428,9 +465,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32", "data": "synthetic",
             "config": {"workload": workload, "pairs": pairs, "cells": cells,
-                       "parallelism": f"pair-range x{world} + RCCL all-gather ({'int16 exchange, widened to s32 on device' if use16 else 's32'}), "
-                                      f"{sched.chunks} overlapped super-chunks, every rank copies its 1/{world} share to page-locked host memory",
-                       "timed_region": "kernels + all-gathers + widen + per-rank device->host copies (GatherStep); inputs resident in HBM",
+                       "parallelism": f"{'tiles of the launch plan dealt over' if tiled else 'contiguous pair ranges on'} {world} ranks + RCCL all-gather "
+                                      f"({'int16 exchange, widened to s32 on device' if use16 else 's32'}), "
+                                      f"{nchunks} overlapped super-chunks, every rank copies its 1/{world} piece to page-locked host memory",
+                       "timed_region": f"kernels + all-gathers + widen-and-place + per-rank device->host copies ({'TiledGatherStep' if tiled else 'GatherStep'}); inputs resident in HBM",
                        **({"super_chunk_trial_ms": tuned} if tuned else {}),
                        "gathered_and_host_result_verified_on_every_rank": gather_ok},
             "gcups": cells / sec / 1e9,

@@ -214,6 +214,23 @@ int sa_method_gap_kind(int method);       /* enum sa_gap_kind               */
  * uploads, allocations and context set-up are outside it, the device->host copies inside). */
 double sa_hip_last_align_seconds(void);
 
+/* Where the time of the last successful sa_hip_align() went, in milliseconds (its first slice): ms[k] for k of
+ * enum sa_breakdown; returns the number of entries written.  Everything but SA_BREAKDOWN_PHASE is set-up the reference
+ * keeps outside bench_align_start()/bench_align_end() as well (src/interface/seqalign_cuda.c:115-168). */
+enum sa_breakdown {
+	SA_BREAKDOWN_ENCODE = 0,   /* validate + residue -> index (the reference uploads SEQ_LUT instead)        */
+	SA_BREAKDOWN_DEVICE,       /* hipSetDevice / runtime bring-up                                            */
+	SA_BREAKDOWN_UPLOAD,       /* device allocations, uploads, streams and events                            */
+	SA_BREAKDOWN_CODE_OBJECTS, /* loading the kernel families this store needs                               */
+	SA_BREAKDOWN_PIN,          /* page-locking the destination (skipped when the caller registered it)       */
+	SA_BREAKDOWN_PLAN,         /* launch plan of the range (tile lists)                                      */
+	SA_BREAKDOWN_ARRANGE,      /* arranged copies of the row store                                           */
+	SA_BREAKDOWN_PHASE,        /* the launch/copy loop = sa_hip_last_align_seconds()                         */
+	SA_BREAKDOWN_TOTAL,        /* create + align_host of the slice                                           */
+	SA_BREAKDOWN_COUNT
+};
+int sa_hip_last_align_breakdown(double *ms, int n);
+
 int sa_hip_device_count(void);
 const char *sa_hip_device_name(int device);
 const char *sa_last_error(void);

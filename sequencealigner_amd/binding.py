@@ -51,7 +51,7 @@ ABI_SYMBOLS = (
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
-    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares",
+    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown",
 )
 
 
@@ -145,6 +145,8 @@ def load_library() -> C.CDLL:
     lib.sa_hip_host_register.restype = C.c_int
     lib.sa_hip_host_unregister.argtypes = [C.c_void_p]
     lib.sa_hip_host_unregister.restype = C.c_int
+    lib.sa_hip_last_align_breakdown.argtypes = [C.POINTER(C.c_double), C.c_int]
+    lib.sa_hip_last_align_breakdown.restype = C.c_int
     lib.sa_ctx_share_elems.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
     lib.sa_ctx_share_elems.restype = C.c_int64
     lib.sa_ctx_align_share.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -166,6 +168,14 @@ def device_count() -> int:
 def last_align_seconds() -> float:
     """launch/copy phase of the last hip_align call (the reference's bench_align bracket, seqalign_cuda.c:182,292)"""
     return float(load_library().sa_hip_last_align_seconds())
+
+
+def last_align_breakdown() -> dict:
+    """milliseconds of the last hip_align call by stage (enum sa_breakdown): set-up itemised, then the phase"""
+    names = ("encode_ms", "device_ms", "upload_ms", "code_objects_ms", "pin_ms", "plan_ms", "arrange_ms", "phase_ms", "total_ms")
+    buf = (C.c_double * len(names))()
+    n = load_library().sa_hip_last_align_breakdown(buf, len(names))
+    return {names[k]: float(buf[k]) for k in range(n)}
 
 
 def device_name(device: int = 0) -> str:

@@ -137,6 +137,10 @@ struct sa_ctx {
 	/* development switches, read once when the context is created */
 	bool env_serial_classes = false, env_stamps = false, env_no_pin = false, env_no_shells = false, env_no_direct = false;
 	int env_chunk = 0;
+	/* where the set-up time of this context went, milliseconds (sa_hip_last_align_breakdown) */
+	struct SetupMs {
+		double encode = 0, device = 0, upload = 0, code_objects = 0, pin = 0, plan = 0, arrange = 0;
+	} setup;
 	/* host delivery (sa_ctx_align_host): streams, events and buffers, created on first use and kept */
 	struct Deliver {
 		hipStream_t compute = nullptr, copy = nullptr;
@@ -152,6 +156,11 @@ struct sa_ctx {
 
 namespace {
 void deliver_release(sa_ctx *ctx);
+}
+
+static double ms_since(std::chrono::steady_clock::time_point t0)
+{
+	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
 static void plan_free(sa_ctx::Plan &pl)
@@ -444,17 +453,22 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	std::vector<uint8_t> codes;
 	std::vector<int32_t> off;
 	int32_t max_len = 0;
+	const auto t_encode = std::chrono::steady_clock::now();
 	if (!validate_and_encode(in, *sc, codes, off, max_len))
 		return nullptr;
+	const double encode_ms = ms_since(t_encode);
 	const bool verbose = getenv("SA_HIP_VERBOSE") != nullptr;
 	const auto t_create = std::chrono::steady_clock::now();
 	auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create).count(); };
 	if (!device_ready(device))
 		return nullptr;
+	const double device_ms = since();
 	if (verbose)
 		fprintf(stderr, "[seqalign_hip] sa_ctx_create: device ready at %.1f ms\n", since());
 
 	sa_ctx *ctx = new sa_ctx();
+	ctx->setup.encode = encode_ms;
+	ctx->setup.device = device_ms;
 	ctx->device = device;
 	ctx->num = in.num;
 	ctx->max_len = max_len;
@@ -535,7 +549,10 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		}
 		if (verbose)
 			fprintf(stderr, "[seqalign_hip] sa_ctx_create: buffers, streams and events at %.1f ms\n", since());
+		ctx->setup.upload = since() - device_ms; /* allocations, uploads, streams and events */
+		const double t_warm = since();
 		SA_HIP_CHECK(sa_warm_kernels(sc->method, families), break);
+		ctx->setup.code_objects = since() - t_warm;
 		if (verbose)
 			fprintf(stderr, "[seqalign_hip] sa_ctx_create: code objects of families %d loaded at %.1f ms\n", families, since());
 		ok = true;
@@ -613,6 +630,12 @@ static bool arranged_store(sa_ctx *ctx, int ng, int ch, int32_t block, const sa_
 	const int32_t wave_rows = ng * ch;
 	if (block <= 0 || block % (wave_rows * SA_PK_WPB) != 0 || block > num)
 		return true; /* no full block: nothing to arrange */
+	const auto t_arr = std::chrono::steady_clock::now();
+	struct Acc {
+		sa_ctx *c;
+		std::chrono::steady_clock::time_point t;
+		~Acc() { c->setup.arrange += ms_since(t); }
+	} acc{ ctx, t_arr };
 	std::vector<int32_t> rowmap((size_t)num), posmap((size_t)num), off_s((size_t)num + 1);
 	for (int32_t i = 0; i < num; i++)
 		rowmap[(size_t)i] = i;
@@ -834,6 +857,14 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 			ctx->plan = &pl;
 			return true;
 		}
+	const auto t_plan = std::chrono::steady_clock::now();
+	const double arrange_before = ctx->setup.arrange;
+	struct Acc {
+		sa_ctx *c;
+		std::chrono::steady_clock::time_point t;
+		double a0;
+		~Acc() { c->setup.plan += ms_since(t) - (c->setup.arrange - a0); }
+	} acc{ ctx, t_plan, arrange_before };
 	constexpr size_t MAX_PLANS = 32;
 	if (ctx->plans.capacity() < MAX_PLANS)
 		ctx->plans.reserve(MAX_PLANS); /* pointers into the vector stay valid */
@@ -1489,8 +1520,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			cells_here = pb->cells[(size_t)rk];
 			a.counter = counters + 2 * (SA_PK_CLASS0 + it.bundle);
 			const int klo_seen = ctx->plan->classes[(size_t)pb->cls.back()].cls - (pb->g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
-			snprintf(name, sizeof(name), "sa_k_systolic_pk_bundle<%s,G%d,K%d-%d%s>", METHOD_TAG[ctx->sc.method], pb->g, klo_seen,
-				 pb->kmax, pb->f16 ? "" : ",u16");
+			/* template arguments as rocprofv3 prints them, then the classes this launch walks */
+			snprintf(name, sizeof(name), "sa_k_systolic_pk_bundle<%s,%d,%d,%s>[K%d-%d]", METHOD_TAG[ctx->sc.method], pb->g, pb->klo,
+				 pb->f16 ? "true" : "false", klo_seen, pb->kmax);
 		} else {
 			const auto &cl = *clp;
 			const int64_t W = is_long ? ((int64_t)ctx->max_len + SA_SYS_LONG_W - 1) / SA_SYS_LONG_W * SA_SYS_LONG_W
@@ -2010,10 +2042,12 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)total : dim * dim);
 		const size_t avail = host_available_bytes();
 		if (!host_range_is_pinned(base) && (!avail || bytes <= avail / 2)) {
+			const auto t_pin = std::chrono::steady_clock::now();
 			if (hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess)
 				pinned_here = base;
 			else
 				(void)hipGetLastError();
+			ctx->setup.pin += ms_since(t_pin);
 		}
 	}
 	/* Packed destination that is page-locked: the kernels store their scores straight into it.  The epilogue's
@@ -2080,6 +2114,8 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 
 /* launch/copy phase of the last successful sa_hip_align call (the reference's bench_align_start..end bracket) */
 static std::atomic<double> g_last_align_seconds{ 0.0 };
+static std::mutex g_breakdown_mutex;
+static double g_breakdown[SA_BREAKDOWN_COUNT] = {};
 
 /* devices sa_hip_align spreads a job over: all visible ones, or the first SA_HIP_DEVICES */
 static int devices_in_use(void)
@@ -2159,13 +2195,16 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 	}
 	/* several slices share one destination: page-lock it once for all of them (set-up, outside the timed phase) */
 	void *pinned_here = nullptr;
+	double pin_all_ms = 0.0;
 	if (ndev > 1 && out.matrix && !getenv("SA_HIP_NO_PIN") && device_ready(0) && !host_range_is_pinned(out.matrix)) {
 		const size_t n = (size_t)in.num;
 		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)pairs : n * n);
+		const auto t_pin = std::chrono::steady_clock::now();
 		if (hipHostRegister(out.matrix, bytes, hipHostRegisterPortable) == hipSuccess)
 			pinned_here = out.matrix;
 		else
 			(void)hipGetLastError();
+		pin_all_ms = ms_since(t_pin);
 	}
 	std::vector<std::string> errs((size_t)ndev);
 	std::vector<char> oks((size_t)ndev, 0);
@@ -2176,11 +2215,19 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 			oks[(size_t)k] = 1;
 			return;
 		}
+		const auto t_slice = std::chrono::steady_clock::now();
 		sa_ctx *ctx = sa_ctx_create(k % nvisible, in, sc);
 		if (ctx && sa_ctx_align_host(ctx, lo, hi - lo, out, &phases[(size_t)k]) == 0)
 			oks[(size_t)k] = 1;
 		else
 			errs[(size_t)k] = sa_last_error();
+		if (ctx && k == 0) { /* the first slice speaks for the call */
+			std::lock_guard<std::mutex> g(g_breakdown_mutex);
+			const double v[SA_BREAKDOWN_COUNT] = { ctx->setup.encode, ctx->setup.device, ctx->setup.upload, ctx->setup.code_objects,
+							       ctx->setup.pin + pin_all_ms, ctx->setup.plan, ctx->setup.arrange, phases[0] * 1e3,
+							       ms_since(t_slice) };
+			memcpy(g_breakdown, v, sizeof(v));
+		}
 		sa_ctx_destroy(ctx);
 	};
 	if (ndev == 1) {
@@ -2206,6 +2253,17 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 		}
 	g_last_align_seconds.store(*std::max_element(phases.begin(), phases.end()));
 	return true;
+}
+
+extern "C" int sa_hip_last_align_breakdown(double *ms, int n)
+{
+	if (!ms || n < 0)
+		return 0;
+	std::lock_guard<std::mutex> g(g_breakdown_mutex);
+	const int m = std::min(n, (int)SA_BREAKDOWN_COUNT);
+	for (int k = 0; k < m; k++)
+		ms[k] = g_breakdown[k];
+	return m;
 }
 
 extern "C" double sa_hip_last_align_seconds(void)

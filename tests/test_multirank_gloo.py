@@ -55,6 +55,54 @@ for c in range(sched.chunks):
 for w in works:
     w.wait()
 assert np.array_equal(buf16[:store.pairs].to(torch.int32).numpy(), full), f"rank {rank}: int16 exchange differs"
+# bench.py's default schedule at N > 1: TiledGatherStep -- tiles dealt over the ranks, dense shares, one all-gather per
+# geometric super-chunk, place into packed order, per-rank host pieces.  The "device" is the oracle behind the same
+# backend interface HipShares implements with sa_ctx_share_elems / sa_ctx_align_share / sa_ctx_place_shares.
+from sequencealigner_amd.distributed import TiledGatherStep, tri
+
+class OracleShares:
+    device = "cpu"
+    def __init__(self, dtype):
+        self.dtype = dtype
+    def _tiles(self, start, count, world):
+        # -> [(owner, share_offset, packed_lo, n)]: (column, block of 16 rows) tiles of the range, dealt round-robin
+        tiles, fill, k = [], [0] * world, 0
+        j = 1
+        while tri(j + 1) <= start:
+            j += 1
+        p = start
+        while p < start + count:
+            hi = min(start + count, tri(j + 1))
+            while p < hi:
+                n = min(16, hi - p)
+                r = k % world
+                tiles.append((r, fill[r], p, n))
+                fill[r] += n
+                k += 1
+                p += n
+            j += 1
+        return tiles, max(fill)
+    def share_elems(self, start, count, world):
+        return self._tiles(start, count, world)[1]
+    def align_share(self, start, count, world, r, share, stream):
+        for owner, off, p, n in self._tiles(start, count, world)[0]:
+            if owner == r:
+                share[off:off + n] = torch.from_numpy(o.align_range(store, scoring, p, n, threads=1)).to(self.dtype)
+    def place(self, start, count, world, shares, packed_range, stream):
+        tiles, e = self._tiles(start, count, world)
+        for owner, off, p, n in tiles:
+            packed_range[p - start:p - start + n] = shares[owner * e + off:owner * e + off + n].to(torch.int32)
+
+for chunks, dtype in ((1, torch.int32), (3, torch.int16)):
+    step = TiledGatherStep(OracleShares(dtype), store.num, world, rank, chunks, dist)
+    step()
+    step()
+    assert np.array_equal(step.packed.numpy(), full), f"rank {rank}: tiled step, {chunks} chunks: placed vector differs"
+    mine = torch.zeros(store.pairs, dtype=torch.int32)
+    for lo, hi, ho in step.host_ranges():
+        mine[lo:hi] = step.host[ho:ho + hi - lo] + 1  # (+1: a delivered zero score still counts as covered)
+    dist.all_reduce(mine)  # the ranks' host pieces tile the packed index exactly once
+    assert np.array_equal(mine.numpy(), full + 1), f"rank {rank}: host pieces of the tiled step do not assemble the matrix"
 # work-balanced cut points (the general driver's rule) cover the index exactly once
 b = store.partition(world)
 assert b[0] == 0 and b[-1] == store.pairs
@@ -97,6 +145,31 @@ def test_chunked_schedule_covers_index_once():
                     assert lo == min(pairs, pos) and hi >= lo
                     pos = hi if hi > lo else pos
                 assert pos == pairs
+
+
+def test_column_chunks_are_column_aligned_geometric_and_cover_the_index():
+    from sequencealigner_amd.distributed import column_chunks, host_piece, tri
+    for n in (2, 3, 17, 1100, 10_000, 100_000):
+        for chunks in (1, 2, 3, 4, 7):
+            r = column_chunks(n, chunks)
+            assert 1 <= len(r) <= chunks
+            pos = 0
+            for lo, cnt in r:
+                assert lo == pos and cnt > 0
+                j = int((1 + (1 + 8 * lo) ** 0.5) / 2)
+                assert any(tri(x) == lo for x in (j - 1, j, j + 1)), "super-chunks start at column starts"
+                pos += cnt
+            assert pos == tri(n)
+            if n >= 1000 and len(r) > 1:
+                assert all(a[1] > 2 * b[1] for a, b in zip(r, r[1:])), "each super-chunk is much smaller than the one before"
+            for world in (1, 2, 8):
+                for lo, cnt in r:
+                    seen = 0
+                    for rank in range(world):
+                        a, b = host_piece(lo, cnt, world, rank)
+                        assert lo <= a <= b <= lo + cnt
+                        seen += b - a
+                    assert seen == cnt
 
 
 def test_rank_ranges_cover_index_once():

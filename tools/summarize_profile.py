@@ -32,10 +32,11 @@ if os.path.exists(tb):
     print(f"\n## dominant kernel under rocprofv3: bench.py (HIP events, timed steps) {roof['kernel']} avg {roof['kernel_avg_ms']:.3f} ms")
     import re
     m = re.match(r"sa_k_systolic<(\w+),G(\d+),K(\d+)>", roof["kernel"])
-    mp = re.match(r"sa_k_systolic_pk<(\w+),K(\d+)>", roof["kernel"])
+    mp = re.match(r"sa_k_systolic_pk_bundle<(\w+),(\d+),(\d+),(\w+)>", roof["kernel"])
     if m or mp:
         meth = {"nw": "0", "ga": "1", "sw": "2"}[(m or mp).group(1)]
-        pat = f"sa_k_systolic<{meth}, {m.group(2)}, {m.group(3)}, false>" if m else f"sa_k_systolic_pk<{meth}, 8, {mp.group(2)}, true>"
+        pat = (f"sa_k_systolic<{meth}, {m.group(2)}, {m.group(3)}, false>" if m else
+               f"sa_k_systolic_pk_bundle<{meth}, {mp.group(2)}, {mp.group(3)}, {mp.group(4)}>")
         for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_trace.csv"), recursive=True):
             durs = [(int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
                     for r in csv.DictReader(open(f)) if pat in r["Kernel_Name"]]
