@@ -160,7 +160,7 @@ def test_column_chunks_are_column_aligned_geometric_and_cover_the_index():
                 assert any(tri(x) == lo for x in (j - 1, j, j + 1)), "super-chunks start at column starts"
                 pos += cnt
             assert pos == tri(n)
-            if n >= 1000 and len(r) > 1:
+            if n >= 1000 and 1 < len(r) <= 4:
                 assert all(a[1] > 2 * b[1] for a, b in zip(r, r[1:])), "each super-chunk is much smaller than the one before"
             for world in (1, 2, 8):
                 for lo, cnt in r:
