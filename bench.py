@@ -393,9 +393,22 @@ def main():
     use16 = ctx.scores_fit16 and not os.environ.get("SA_BENCH_GATHER32")
     tiled = os.environ.get("SA_BENCH_PARTITION", "tiled") != "range"  # "range": contiguous packed ranges per rank (A/B)
 
+    # the host matrix of the tiled step: ONE packed matrix for the node, a shared mapping under /dev/shm that every rank
+    # attaches and page-locks (the reference's single mmap-ed result, io/output.c:55); every rank's kernels store the
+    # scores that rank computed straight into it, so together the ranks fill it exactly once
+    host = None
+    if tiled:
+        shm = f"/dev/shm/sa_bench_matrix_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.bin"
+        if rank == 0:
+            host = sa.PinnedMatrix(pairs, shared=shm, create=True)
+        fence()
+        if rank != 0:
+            host = sa.PinnedMatrix(pairs, shared=shm, create=False)
+        fence()
+
     def make_step(c):
         if tiled:
-            return TiledGatherStep(HipShares(ctx, use16), store.num, world, rank, c, dist)
+            return TiledGatherStep(HipShares(ctx, use16, host), store.num, world, rank, c, dist)
         return GatherStep(ctx, pairs, world, rank, c, dist, use16)
 
     # super-chunks per step: more of them hide more of the all-gather / place / host copy behind the kernels but add
@@ -438,9 +451,10 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # every rank re-scores a few random windows of the gathered vector with its own kernels (untimed) and compares, and
-    # checks its host share against the gathered vector: the result of the last step must be the packed matrix in
-    # natural order on every GPU and on the host.  (The oracle-backed check of this schedule: tests/test_gpu_gather_step.py)
+    # every rank re-scores a few random windows of the gathered vector with its own kernels (untimed) and compares; the
+    # host matrix -- filled by all ranks' direct stores during the last step -- must equal the gathered vector element
+    # for element: rank r checks slice r of it.  (The oracle-backed check of this schedule: tests/test_gpu_gather_step.py,
+    # the reference-digest check of placed shares and host matrix: tests/test_gpu_digests.py)
     vrng = np.random.default_rng(1234 + rank)
     okflag = 1
     for _ in range(6):
@@ -451,12 +465,28 @@ def main():
         torch.cuda.synchronize()
         if not torch.equal(chk, step.packed[a0:a0 + w]):
             okflag = 0
-    for lo, hi, ho in step.host_ranges():
-        if not torch.equal(step.host[ho:ho + hi - lo], step.packed[lo:hi].cpu()):
+    fence()
+    if tiled:
+        per = (pairs + world - 1) // world
+        lo, hi = min(pairs, rank * per), min(pairs, (rank + 1) * per)
+        if not np.array_equal(host.array[lo:hi], step.packed[lo:hi].cpu().numpy()):
             okflag = 0
+    else:
+        for lo, hi, ho in step.host_ranges():
+            if not torch.equal(step.host[ho:ho + hi - lo], step.packed[lo:hi].cpu()):
+                okflag = 0
     t = torch.tensor([okflag], dtype=torch.int32, device="cuda")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     gather_ok = bool(t.item())
+    # rank 0: the assembled host matrix against the reference's per-column digests of this workload, when the build
+    # container committed them (tests/golden/digest_<config>.npz) -- every pair, bit for bit, no sampling
+    digest_ok = None
+    dpath = ROOT / "tests" / "golden" / f"digest_{args.config}.npz"
+    if tiled and rank == 0 and args.n is None and dpath.exists():
+        from tests.digest_util import column_digests
+        z = np.load(dpath)
+        got = column_digests(host.array, store.num)
+        digest_ok = all(bool(np.array_equal(got[k], z[k])) for k in ("sum", "xor", "crc32"))
 
     if rank == 0:
         sec = elapsed / args.steps
@@ -467,10 +497,11 @@ def main():
             "config": {"workload": workload, "pairs": pairs, "cells": cells,
                        "parallelism": f"{'tiles of the launch plan dealt over' if tiled else 'contiguous pair ranges on'} {world} ranks + RCCL all-gather "
                                       f"({'int16 exchange, widened to s32 on device' if use16 else 's32'}), "
-                                      f"{nchunks} overlapped super-chunks, every rank copies its 1/{world} piece to page-locked host memory",
-                       "timed_region": f"kernels + all-gathers + widen-and-place + per-rank device->host copies ({'TiledGatherStep' if tiled else 'GatherStep'}); inputs resident in HBM",
+                                      f"{nchunks} overlapped super-chunks, " + ("every rank's kernels store its scores straight into the one page-locked host matrix (shared mapping)" if tiled else f"every rank copies its 1/{world} share to page-locked host memory"),
+                       "timed_region": f"kernels (with host delivery) + all-gathers + widen-and-place ({'TiledGatherStep' if tiled else 'GatherStep'}); inputs resident in HBM",
                        **({"super_chunk_trial_ms": tuned} if tuned else {}),
-                       "gathered_and_host_result_verified_on_every_rank": gather_ok},
+                       "gathered_and_host_result_verified_on_every_rank": gather_ok,
+                       "host_matrix_equals_reference_digests": digest_ok},
             "gcups": cells / sec / 1e9,
             "roofline": roofline_of(tm, store, args.steps, args.config, world, args.n is None),
             "valu": valu_of(method, my_cells, sec),
@@ -480,6 +511,13 @@ def main():
         print(json.dumps(out), flush=True)
     ctx.close()
     dist.barrier()
+    if host is not None:
+        host.close()
+        if rank == 0:
+            try:
+                os.unlink(host.path)
+            except OSError:
+                pass
     dist.destroy_process_group()
 
 

@@ -163,11 +163,24 @@ int sa_hip_widen16(const int16_t *d_src, int32_t *d_dst, int64_t count, void *st
  * order, into d_share: sa_ctx_share_elems() elements (the same on every rank) of int16 (elem16 != 0; needs
  * sa_ctx_scores_fit16) or s32.  After an all-gather of the shares (rank-major, world x share_elems elements),
  * sa_ctx_place_shares widens and places them: d_packed[p - start] = score of pair p, the reference's packed order
- * (src/io/output.c:83).  world = 1 is allowed (one share holding every tile).  All asynchronous on `stream`. */
-int64_t sa_ctx_share_elems(sa_ctx *ctx, int64_t start, int64_t count, int world);
-int sa_ctx_align_share(sa_ctx *ctx, int64_t start, int64_t count, int world, int rank, void *d_share, int elem16, void *stream);
-int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, int world, const void *d_shares, int elem16,
+ * (src/io/output.c:83).  Host delivery (the device->host copies inside the reference's timed loop,
+ * src/interface/seqalign_cuda.c:266-283): with host_packed != NULL -- the WHOLE packed host matrix, page-locked
+ * (sa_hip_host_register), e.g. one shared mapping all ranks of a node attach -- the kernels of a rank also store its
+ * own scores straight into host_packed[p], as sa_ctx_align_host does for one device: together the ranks fill the
+ * matrix exactly once, with no copy pass and without waiting for the gather.  `to_host` of the other two calls must
+ * say whether the shares are computed that way (the plan differs: tiles are then their own arranged row blocks).
+ * world = 1 is allowed (one share holding every tile).  All asynchronous on `stream`. */
+int64_t sa_ctx_share_elems(sa_ctx *ctx, int64_t start, int64_t count, int world, int to_host);
+int sa_ctx_align_share(sa_ctx *ctx, int64_t start, int64_t count, int world, int rank, void *d_share, int elem16,
+		       int32_t *host_packed, void *stream);
+int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, int world, int to_host, const void *d_shares, int elem16,
 			int32_t *d_packed, void *stream);
+
+/* on != 0: the launches this context issues from now on run three instead of four persistent workgroups per CU, leaving
+ * LDS and wave slots for kernels of OTHER streams to run beside them -- the RCCL all-gather and sa_ctx_place_shares of the
+ * previous super-chunk in an overlapped multi-GPU schedule.  (Four per CU fill the LDS: a concurrent kernel then waits
+ * for the launch to end.)  Costs the NW kernels ~8 %, Gotoh / SW ~1 %; off by default. */
+void sa_ctx_leave_room(sa_ctx *ctx, int on);
 
 /* Packed triangular (device) -> full symmetric dim x dim with zero diagonal
  * (device), the layout of src/io/output.c:76-81.  Asynchronous on `stream`. */

@@ -51,7 +51,7 @@ ABI_SYMBOLS = (
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
-    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown",
+    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown", "sa_ctx_leave_room",
 )
 
 
@@ -147,11 +147,13 @@ def load_library() -> C.CDLL:
     lib.sa_hip_host_unregister.restype = C.c_int
     lib.sa_hip_last_align_breakdown.argtypes = [C.POINTER(C.c_double), C.c_int]
     lib.sa_hip_last_align_breakdown.restype = C.c_int
-    lib.sa_ctx_share_elems.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    lib.sa_ctx_leave_room.argtypes = [C.c_void_p, C.c_int]
+    lib.sa_ctx_leave_room.restype = None
+    lib.sa_ctx_share_elems.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
     lib.sa_ctx_share_elems.restype = C.c_int64
-    lib.sa_ctx_align_share.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    lib.sa_ctx_align_share.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.sa_ctx_align_share.restype = C.c_int
-    lib.sa_ctx_place_shares.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    lib.sa_ctx_place_shares.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.sa_ctx_place_shares.restype = C.c_int
     _lib = lib
     return lib
@@ -345,15 +347,30 @@ def hip_align(store: SequenceStore, scoring: Scoring, triangular: bool = False, 
 
 class PinnedMatrix:
     """A host result matrix page-locked once (what a C host does in output_load with sa_hip_host_register), so that
-    repeated deliveries into it are pure DMA.  `.array` is the flat int32 numpy view."""
+    repeated deliveries into it are pure DMA / direct stores.  `.array` is the flat int32 numpy view.
 
-    def __init__(self, elements: int):
+    `shared=path`: the matrix is a shared file mapping (e.g. under /dev/shm) that every rank of a node attaches and
+    page-locks -- one host matrix for a one-process-per-GPU run, the reference's single mmap-ed result
+    (src/io/output.c:55) -- created by the rank that passes create=True, zero-filled."""
+
+    def __init__(self, elements: int, shared: Optional[str] = None, create: bool = True):
         self._lib = load_library()
-        self.array = np.zeros(max(int(elements), 1), dtype=np.int32)[:int(elements)]
+        if shared is not None:
+            if create:
+                with open(shared, "wb") as f:
+                    f.truncate(4 * max(int(elements), 1))
+            self.array = np.memmap(shared, dtype=np.int32, mode="r+", shape=(max(int(elements), 1),))[:int(elements)]
+        else:
+            self.array = np.zeros(max(int(elements), 1), dtype=np.int32)[:int(elements)]
+        self.path = shared
         self._registered = False
         if elements and self._lib.sa_hip_host_register(C.c_void_p(self.array.ctypes.data), self.array.nbytes):
             raise AlignError(_err())
         self._registered = bool(elements)
+
+    @property
+    def ptr(self) -> int:
+        return int(self.array.ctypes.data)
 
     def close(self) -> None:
         if self._registered:
@@ -430,21 +447,29 @@ class Context:
             raise AlignError(_err())
 
     # ---- tile-interleaved sharding (one process per GPU; sequencealigner_amd/distributed.py: TiledGatherStep) ----
-    def share_elems(self, start: int, count: int, world: int) -> int:
+    def leave_room(self, on: bool) -> None:
+        """three instead of four persistent workgroups per CU from now on: room for a concurrent collective / placement"""
+        self._lib.sa_ctx_leave_room(self._h, int(on))
+
+    def share_elems(self, start: int, count: int, world: int, to_host: bool = False) -> int:
         """elements of one rank's dense share of the packed range (the same on every rank)"""
-        v = int(self._lib.sa_ctx_share_elems(self._h, start, count, world))
+        v = int(self._lib.sa_ctx_share_elems(self._h, start, count, world, int(to_host)))
         if v < 0:
             raise AlignError(_err())
         return v
 
-    def align_share(self, start: int, count: int, world: int, rank: int, d_share_ptr: int, elem16: bool, stream: int = 0) -> None:
-        """scores of `rank`'s tiles of the range, densely in tile order (int16 or s32 elements)"""
-        if self._lib.sa_ctx_align_share(self._h, start, count, world, rank, C.c_void_p(d_share_ptr), int(elem16), C.c_void_p(stream)):
+    def align_share(self, start: int, count: int, world: int, rank: int, d_share_ptr: int, elem16: bool, stream: int = 0,
+                    host_packed_ptr: int = 0) -> None:
+        """scores of `rank`'s tiles of the range, densely in tile order (int16 or s32 elements); with host_packed_ptr (the
+        WHOLE page-locked packed host matrix) the same scores also go straight to host_packed[p]"""
+        if self._lib.sa_ctx_align_share(self._h, start, count, world, rank, C.c_void_p(d_share_ptr), int(elem16),
+                                        C.c_void_p(host_packed_ptr or None), C.c_void_p(stream)):
             raise AlignError(_err())
 
-    def place_shares(self, start: int, count: int, world: int, d_shares_ptr: int, elem16: bool, d_packed_ptr: int, stream: int = 0) -> None:
+    def place_shares(self, start: int, count: int, world: int, d_shares_ptr: int, elem16: bool, d_packed_ptr: int, stream: int = 0,
+                     to_host: bool = False) -> None:
         """gathered shares (rank-major) -> d_packed[p - start], the reference's packed order, widened to s32"""
-        if self._lib.sa_ctx_place_shares(self._h, start, count, world, C.c_void_p(d_shares_ptr), int(elem16),
+        if self._lib.sa_ctx_place_shares(self._h, start, count, world, int(to_host), C.c_void_p(d_shares_ptr), int(elem16),
                                          C.c_void_p(d_packed_ptr), C.c_void_p(stream)):
             raise AlignError(_err())
 

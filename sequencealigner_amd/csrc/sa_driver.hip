@@ -19,6 +19,10 @@
 
 #include "sa_internal.h"
 #include <atomic>
+#include <csignal>
+#include <execinfo.h>
+#include <fcntl.h>
+#include <unistd.h>
 #include <chrono>
 
 /* The class launches of a range run concurrently, one stream each; the HIP runtime multiplexes streams onto
@@ -26,9 +30,28 @@
  * after the other: with the default, cfg 2's six classes ran as two rounds of three, each round with its own tail
  * (profiles/r03a_*).  The variable is read when the runtime initialises, so it is set when this library is loaded --
  * unless the user has set it. */
+/* SA_HIP_ABORT_TRACE=<file> (diagnostics): a C backtrace of whoever raises SIGABRT in this process, appended to the file */
+static char g_abort_trace_path[512];
+static void sa_abort_trace(int)
+{
+	void *frames[64];
+	const int n = backtrace(frames, 64);
+	const int fd = open(g_abort_trace_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+	if (fd >= 0) {
+		backtrace_symbols_fd(frames, n, fd);
+		close(fd);
+	}
+	signal(SIGABRT, SIG_DFL);
+	raise(SIGABRT);
+}
+
 __attribute__((constructor)) static void sa_runtime_knobs(void)
 {
 	setenv("GPU_MAX_HW_QUEUES", "12", 0);
+	if (const char *p = getenv("SA_HIP_ABORT_TRACE")) {
+		snprintf(g_abort_trace_path, sizeof(g_abort_trace_path), "%s", p);
+		signal(SIGABRT, sa_abort_trace);
+	}
 }
 
 struct sa_ctx {
@@ -86,12 +109,15 @@ struct sa_ctx {
 		int cls = 0;
 		int32_t ncols = 0, ntiles = 0;
 		int32_t npart = 0; /* packed classes: partial tiles among ntiles (listed behind the tile prefix) */
+		int32_t chunk = 0; /* packed classes: sequences per row stream of a full tile */
 		int64_t pairs = 0, cells = 0;
 		int32_t *d_jlist = nullptr, *d_tprefix = nullptr;
 		/* share plans (tile-interleaved sharding): the tiles of rank 0, rank 1, ... back to back; rank r runs
 		 * d_tlist[rank_first[r] .. rank_first[r + 1]) and stores tile t at d_doff[t] of its dense share */
 		int32_t *d_tlist = nullptr;
 		int64_t *d_doff = nullptr;
+		std::vector<int32_t> part_rows;  /* packed classes: rows of the partial tiles, in tile order (decreasing)  */
+		std::vector<int16_t> owner;      /* share plans: rank of every tile                                        */
 		std::vector<int32_t> rank_first;
 		std::vector<int64_t> rank_pairs, rank_cells;
 	};
@@ -99,12 +125,15 @@ struct sa_ctx {
 		int64_t start = -1, count = -1;
 		int32_t chunk = SA_SYS_CHUNK; /* sequences per group stream chosen for this range */
 		int32_t chunk_pk = SA_SYS_CHUNK; /* ... for the packed classes (their tiles are workgroup-tiles of two columns) */
+		int32_t chunk_pk_small = 0;      /* ... and for their columns below j_small: the tiles that end the launch (0: none) */
+		int32_t j_small = 0;
 		std::vector<ClassLaunch> classes;
 		std::vector<std::pair<int64_t, int64_t>> generic; /* (start, count) runs for the generic kernels */
 		uint64_t stamp = 0;
 		/* share plans: world > 0.  Every rank's dense share is share_elems elements long (the longest one's length);
 		 * segs places the gathered shares (rank-major) into packed order */
 		int world = 0;
+		bool share_host = false; /* share plans: the ranks also deliver to a host matrix (tiles are their own arranged blocks) */
 		int64_t share_elems = 0;
 		SaPlaceSeg *d_segs = nullptr;
 		int32_t nsegs = 0;
@@ -116,7 +145,9 @@ struct sa_ctx {
 		struct PkLaunch {
 			int g = 8, klo = 1, f16 = 1, kmax = 1;
 			std::vector<int> cls;          /* indices into `classes`, walking order                       */
-			SaPkClassArgs *d_args = nullptr; /* max(world, 1) arrays of cls.size() entries, rank-major     */
+			SaPkClassArgs *d_args = nullptr; /* cls.size() entries                                          */
+			uint32_t *d_ulist = nullptr;   /* the tiles in walking order, rank after rank                 */
+			std::vector<int64_t> ufirst;   /* max(world, 1) + 1 offsets into d_ulist                      */
 			std::vector<int32_t> nlocal;   /* tiles of the launch, per rank (one entry when world == 0)   */
 			std::vector<int64_t> pairs, cells;
 		};
@@ -136,7 +167,8 @@ struct sa_ctx {
 	std::vector<Timed> events;
 	/* development switches, read once when the context is created */
 	bool env_serial_classes = false, env_stamps = false, env_no_pin = false, env_no_shells = false, env_no_direct = false;
-	int env_chunk = 0;
+	int env_chunk = 0, env_stagger = 0, env_pk_wgs = 0;
+	bool leave_room = false; /* sa_ctx_leave_room */
 	/* where the set-up time of this context went, milliseconds (sa_hip_last_align_breakdown) */
 	struct SetupMs {
 		double encode = 0, device = 0, upload = 0, code_objects = 0, pin = 0, plan = 0, arrange = 0;
@@ -163,6 +195,19 @@ static double ms_since(std::chrono::steady_clock::time_point t0)
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+/* is the byte at p page-locked and known to the HIP runtime (hipHostMalloc / hipHostRegister)?  Callers that hand a
+ * RANGE to the kernels probe its first and its last element: a destination registered only in part must not take the
+ * direct-store path (a GPU page fault instead of a fallback). */
+static bool host_range_is_pinned(const void *p)
+{
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+		(void)hipGetLastError();
+		return false;
+	}
+	return attr.type == hipMemoryTypeHost;
+}
+
 static void plan_free(sa_ctx::Plan &pl)
 {
 	for (auto &c : pl.classes) {
@@ -172,8 +217,10 @@ static void plan_free(sa_ctx::Plan &pl)
 		(void)hipFree(c.d_doff);
 	}
 	(void)hipFree(pl.d_segs);
-	for (auto &b : pl.pk_launches)
+	for (auto &b : pl.pk_launches) {
 		(void)hipFree(b.d_args);
+		(void)hipFree(b.d_ulist);
+	}
 	pl = sa_ctx::Plan();
 }
 
@@ -359,6 +406,21 @@ static int systolic_class_for(int32_t n)
 	return SA_SYS_CLASS_LONG;
 }
 
+/* a packed class of a plan: lane-group width, columns per lane, and whether it is the small-tile copy of the class */
+struct PkCls {
+	bool small;
+	int g, k;
+};
+static PkCls pk_decode(int cls)
+{
+	PkCls r;
+	r.small = cls >= SA_PK_CLASSES_END;
+	const int c = r.small ? cls - SA_PK_SMALL : cls;
+	r.g = c >= SA_PK16_CLASS0 ? 16 : 8;
+	r.k = c - (r.g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
+	return r;
+}
+
 /* frame shifts a value of the packed kernels can see before its last use: its own terminator entering the group plus
  * one per later terminator entering while its last rows travel through the remaining G - 1 lanes.  Terminators are
  * min_len + 1 stream positions apart at least (every sequence is a row of some stream): 4 / 8 shifts for 8- / 16-lane
@@ -488,6 +550,10 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	ctx->env_no_shells = getenv("SA_HIP_NO_SHELLS") != nullptr;
 	ctx->env_no_direct = getenv("SA_HIP_NO_DIRECT") != nullptr;
 	ctx->env_no_sort = getenv("SA_HIP_NO_SORT") != nullptr;
+	if (const char *e = getenv("SA_HIP_PK_WGS")) /* development switch: persistent workgroups of a packed launch */
+		ctx->env_pk_wgs = std::max(0, atoi(e));
+	if (const char *e = getenv("SA_HIP_STAGGER"))
+		ctx->env_stagger = std::max(0, std::min(64, atoi(e)));
 	if (const char *e = getenv("SA_HIP_CHUNK")) /* development switch: fixed stream length */
 		ctx->env_chunk = std::max(1, std::min(SA_SYS_CHUNK, atoi(e)));
 	systolic_setup(ctx);
@@ -845,14 +911,16 @@ extern "C" int sa_ctx_timing_read(sa_ctx *ctx, char *kernel_name, int cap, int64
 
 /* ---- launch planning for a packed range ------------------------------------------------- */
 
-static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool host_out, SaSysArgs &a);
+static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool host_out, SaArranged (&lv)[SA_PK_SORT_LEVELS]);
 
 /* world = 0: the plan of sa_ctx_align_range (every tile, packed order).  world >= 1: a SHARE plan -- the same tile lists
- * dealt over `world` ranks, dense tile-order output, placement segments (sa_ctx_align_share / sa_ctx_place_shares). */
-static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
+ * dealt over `world` ranks, dense tile-order output, placement segments (sa_ctx_align_share / sa_ctx_place_shares).
+ * share_host: the scores (also) go straight to host memory -- arranged tiles are then their own blocks and leave in row
+ * order; the arranged copies a plan's classes point to depend on it, so it is part of the plan's key. */
+static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, bool share_host)
 {
 	for (auto &pl : ctx->plans)
-		if (pl.start == start && pl.count == count && pl.world == world) {
+		if (pl.start == start && pl.count == count && pl.world == world && pl.share_host == share_host) {
 			pl.stamp = ++ctx->plan_clock;
 			ctx->plan = &pl;
 			return true;
@@ -898,15 +966,43 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 			chunk = ctx->env_chunk;
 		plan.chunk = chunk;
 		/* packed classes: a workgroup-tile covers 2 columns x SA_PK_WPB * 8 streams of `chunk` sequences and ~4
-		 * workgroups are resident per CU: keep >= 8 tiles per resident workgroup so that a small range (one rank's
+		 * workgroups are resident per CU: keep >= 5 tiles per resident workgroup so that a small range (one rank's
 		 * share at 8 GPUs, a super-chunk) still drains evenly */
-		const int64_t want_pk = (int64_t)ctx->persistent_wgs; /* = 32 x CUs = 8 x (4 workgroups per CU) */
+		/* (measured, cfg 2: quarter tiles cost 5 % more than full ones -- 15.37 against 14.61 ms for the whole range -- and
+		 * half tiles 1 %; one rank's share at 8 ranks takes 2.06 ms in quarter tiles, 1.98 in half or full tiles) */
+		const int64_t want_pk = (int64_t)ctx->persistent_wgs * 5 / 8; /* 32 x CUs x 5 / 8 = 5 x (4 workgroups per CU) */
 		int32_t cpk = SA_SYS_CHUNK;
 		while (cpk > 4 && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < want_pk)
 			cpk >>= 1;
 		if (ctx->env_chunk)
 			cpk = ctx->env_chunk;
 		plan.chunk_pk = cpk;
+		/* Two tile sizes for a launch that gives a workgroup slot fewer than ~24 tiles (one rank's share of a multi-GPU
+		 * run; a super-chunk): when the tiles run out the slots finish their last ones over a whole tile's duration, and
+		 * only work in small units can fill that triangle.  So the bulk runs in tiles as large as leave >= 2.5 per slot,
+		 * and the lowest columns of the range -- a fifth of its pairs -- in tiles a quarter of that size, which the
+		 * launch order puts last (small tiles cost more per row, +5 % at a quarter of the full size, so not everywhere). */
+		const int64_t slots = (int64_t)ctx->persistent_wgs / 8;
+		if (!ctx->env_chunk && !getenv("SA_HIP_ONE_TILE_SIZE") && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < 24 * slots) {
+			int32_t big = SA_SYS_CHUNK;
+			while (big > 16 && 2 * mine / ((int64_t)2 * SA_PK_WPB * 8 * big) < 5 * slots)
+				big >>= 1;
+			big = std::max(big, cpk);
+			if (big >= 16) {
+				plan.chunk_pk = big;
+				plan.chunk_pk_small = std::max(4, big / 4);
+				const int64_t jlo = column_of(start), jhi = column_of(end - 1) + 1;
+				int64_t lo = jlo, hi = jhi; /* smallest column with >= a fifth of the range's pairs below it */
+				while (lo < hi) {
+					const int64_t mid = (lo + hi) / 2;
+					if (mid * (mid - 1) / 2 - start >= count / 5)
+						hi = mid;
+					else
+						lo = mid + 1;
+				}
+				plan.j_small = (int32_t)lo;
+			}
+		}
 	}
 	const int32_t j0 = column_of(start), j1 = column_of(end - 1);
 	for (int32_t j = j0; j <= j1; j++) {
@@ -919,7 +1015,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 		if (k8 <= ctx->pk_kmax || (k16 >= SA_PK_K16_MIN && k16 <= ctx->pk16_kmax)) {
 			/* packed-u16 class K = ceil(n / 8) (8-lane groups) or ceil(n / 16) (16-lane groups): tiles are counted per
 			 * column PAIR below */
-			const size_t pc = (size_t)(k8 <= ctx->pk_kmax ? SA_PK_CLASS0 + k8 : SA_PK16_CLASS0 + k16);
+			const size_t pc = (size_t)(k8 <= ctx->pk_kmax ? SA_PK_CLASS0 + k8 : SA_PK16_CLASS0 + k16) + (j < plan.j_small ? SA_PK_SMALL : 0);
 			jl[pc].push_back(j);
 			rows_of[pc].emplace_back((int32_t)ia, (int32_t)ib);
 			cpairs[pc] += ib - ia;
@@ -953,11 +1049,13 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 	 * ranges, SA_PK_WPB * 8 streams of `chunk` sequences per workgroup-tile.  The prefix counts the full tiles; the
 	 * partial last tiles follow them in the tile numbering, largest first (their pairs are appended to the prefix). */
 	std::vector<int32_t> nparts((size_t)SA_PLAN_NCLASSES, 0);
+	std::vector<std::vector<int32_t>> part_rows((size_t)SA_PLAN_NCLASSES);
 	for (int cls = SA_PK_CLASS0; cls < SA_PLAN_NCLASSES; cls++) {
 		const auto &rw = rows_of[(size_t)cls];
 		if (rw.empty())
 			continue;
-		const int64_t rows = (int64_t)SA_PK_WPB * (cls >= SA_PK16_CLASS0 ? 4 : 8) * plan.chunk_pk;
+		const PkCls pc = pk_decode(cls);
+		const int64_t rows = (int64_t)SA_PK_WPB * (64 / pc.g) * (pc.small ? plan.chunk_pk_small : plan.chunk_pk);
 		tp[(size_t)cls].push_back(0);
 		std::vector<std::pair<int32_t, int32_t>> parts; /* (rows, pair) */
 		for (size_t c = 0; c < rw.size(); c += 2) {
@@ -973,8 +1071,10 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 				parts.emplace_back((int32_t)(span % rows), (int32_t)(c / 2));
 		}
 		std::stable_sort(parts.begin(), parts.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
-		for (const auto &pt : parts)
+		for (const auto &pt : parts) {
 			tp[(size_t)cls].push_back(pt.second);
+			part_rows[(size_t)cls].push_back(pt.first);
+		}
 		nparts[(size_t)cls] = (int32_t)parts.size();
 	}
 	bool ok = true;
@@ -988,6 +1088,12 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 		cl.ntiles = cl.npart ? tp[(size_t)cls][tp[(size_t)cls].size() - 1 - (size_t)cl.npart] + cl.npart : tp[(size_t)cls].back();
 		cl.pairs = cpairs[(size_t)cls];
 		cl.cells = ccells[(size_t)cls];
+		cl.part_rows = part_rows[(size_t)cls];
+		cl.chunk = cls >= SA_PK_CLASS0 ? (pk_decode(cls).small ? plan.chunk_pk_small : plan.chunk_pk) : 0;
+		if (cl.ntiles > (1 << SA_PK_UTILE_BITS) && cls >= SA_PK_CLASS0) {
+			sa_set_error("packed range too large for one launch; split it into smaller ranges");
+			ok = false;
+		}
 		SA_HIP_CHECK(hipMalloc(&cl.d_jlist, sizeof(int32_t) * jl[(size_t)cls].size()), ok = false);
 		if (ok) {
 			SA_HIP_CHECK(hipMalloc(&cl.d_tprefix, sizeof(int32_t) * tp[(size_t)cls].size()), ok = false);
@@ -1009,6 +1115,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 	plan.start = start;
 	plan.count = count;
 	plan.world = world;
+	plan.share_host = share_host;
 	plan.stamp = ++ctx->plan_clock;
 	/* ---- share plan: deal the tiles of every class over the ranks, lay out the dense shares, list the placement ---- */
 	if (ok && world >= 1) {
@@ -1020,7 +1127,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 		struct Geo {
 			int32_t cls_idx, t, owner;
 			int32_t j[2], ia[2], ib[2], i_begin, i_count;
-			bool dup;
+			bool dup, own; /* own: an arranged tile that is its whole block (its rows are a permutation of its positions) */
 			const int32_t *rowmap;
 			int64_t doff;
 		};
@@ -1029,21 +1136,21 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 			auto &cl = plan.classes[ci];
 			const int cls = cl.cls;
 			const bool is_pk = cls >= SA_PK_CLASS0;
-			const int pk_g = cls >= SA_PK16_CLASS0 ? 16 : 8;
+			const int pk_g = is_pk ? pk_decode(cls).g : 8;
 			const int G = is_pk ? pk_g : cls == SA_SYS_CLASS_LONG ? 64 : SA_SYS_CLASSES[cls].G;
-			const int K = is_pk ? cls - (pk_g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0) : cls == SA_SYS_CLASS_LONG ? 16 : SA_SYS_CLASSES[cls].K;
+			const int K = is_pk ? pk_decode(cls).k : cls == SA_SYS_CLASS_LONG ? 16 : SA_SYS_CLASSES[cls].K;
 			const int64_t weight = (int64_t)(K + 6) * (G / 8);
 			const auto &J = jl[(size_t)cls];
 			const auto &T = tp[(size_t)cls];
 			std::vector<Geo> tiles((size_t)cl.ntiles);
 			if (is_pk) {
-				SaSysArgs a{};
-				if (!pk_arranged_levels(ctx, pk_g, plan.chunk_pk, false, a)) {
+				SaArranged lv[SA_PK_SORT_LEVELS];
+				if (!pk_arranged_levels(ctx, pk_g, cl.chunk, share_host, lv)) {
 					ok = false;
 					break;
 				}
-				const int32_t lvrows[SA_PK_SORT_LEVELS] = { a.lv[0].rows, a.lv[1].rows, a.lv[2].rows, a.lv[3].rows };
-				const int32_t rows = SA_PK_WPB * (64 / pk_g) * plan.chunk_pk;
+				const int32_t lvrows[SA_PK_SORT_LEVELS] = { lv[0].rows, lv[1].rows, lv[2].rows, lv[3].rows };
+				const int32_t rows = SA_PK_WPB * (64 / pk_g) * cl.chunk;
 				const auto &rw = rows_of[(size_t)cls];
 				const int32_t npairs = (cl.ncols + 1) / 2, nfull = T[(size_t)npairs];
 				for (int32_t t = 0; t < cl.ntiles; t++) {
@@ -1063,7 +1170,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 					g.i_begin = ra + chunk * rows;
 					g.i_count = std::min(rows, rb - g.i_begin);
 					const int l = sa_pk_pick_level(lvrows, ra, rb, g.i_begin, rows);
-					g.rowmap = l >= 0 ? a.lv[l].rowmap : nullptr;
+					g.rowmap = l >= 0 ? lv[l].rowmap : nullptr;
+					g.own = l >= 0 && lv[l].rows == g.i_count;
 				}
 			} else {
 				const int rows = cls == SA_SYS_CLASS_LONG ? SA_SYS_WPB(64, true) * std::min(plan.chunk, 16)
@@ -1080,6 +1188,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 						g.i_begin = ia + (t - T[(size_t)k]) * rows;
 						g.i_count = std::min(rows, ib - g.i_begin);
 						g.rowmap = nullptr;
+						g.own = false;
 					}
 				}
 			}
@@ -1087,6 +1196,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 			std::vector<int64_t> doff((size_t)cl.ntiles, 0);
 			cl.rank_pairs.assign((size_t)world, 0);
 			cl.rank_cells.assign((size_t)world, 0);
+			cl.owner.assign((size_t)cl.ntiles, 0);
 			for (int32_t t = 0; t < cl.ntiles; t++) {
 				Geo &g = tiles[(size_t)t];
 				/* (arranged tiles hold a permutation of their block's rows: the residue count of the position range is that
@@ -1100,6 +1210,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 				g.cls_idx = (int32_t)ci;
 				g.t = t;
 				g.owner = r;
+				cl.owner[(size_t)t] = (int16_t)r;
 				g.doff = fill[(size_t)r];
 				doff[(size_t)t] = g.doff;
 				fill[(size_t)r] += (int64_t)(g.dup ? 1 : 2) * SA_SHARE_PAD(g.i_count);
@@ -1155,6 +1266,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 				sg.pos0 = g.i_begin;
 				sg.ia = g.ia[h];
 				sg.ib = g.ib[h];
+				sg.flags = g.own ? 1 : 0;
 				segs.push_back(sg);
 			}
 		for (int r = 0; r < world; r++)
@@ -1185,11 +1297,13 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 		for (size_t ci = 0; ci < plan.classes.size(); ci++)
 			if (plan.classes[ci].cls >= SA_PK_CLASS0)
 				order.push_back((int)ci);
+		/* (the small-tile copies of the classes sort behind all the others: their full tiles end the full tiles) */
 		std::sort(order.begin(), order.end(), [&](int x, int y) { return plan.classes[(size_t)x].cls > plan.classes[(size_t)y].cls; });
+		std::stable_partition(order.begin(), order.end(), [&](int x) { return !pk_decode(plan.classes[(size_t)x].cls).small; });
 		for (int ci : order) {
 			const auto &cl = plan.classes[(size_t)ci];
-			const int g = cl.cls >= SA_PK16_CLASS0 ? 16 : 8;
-			const int k = cl.cls - (g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
+			const int g = pk_decode(cl.cls).g;
+			const int k = pk_decode(cl.cls).k;
 			const int klo = sa_pk_bundle_klo(g, k);
 			const int f16 = g == 8 || k <= ctx->pk16_f16_kmax ? 1 : 0;
 			sa_ctx::Plan::PkLaunch *b = nullptr;
@@ -1205,43 +1319,80 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world = 0)
 			b->cls.push_back(ci);
 		}
 		for (auto &b : plan.pk_launches) {
-			std::vector<SaPkClassArgs> args((size_t)nranks * b.cls.size());
+			std::vector<SaPkClassArgs> args(b.cls.size());
+			for (size_t x = 0; x < b.cls.size(); x++) {
+				const auto &cl = plan.classes[(size_t)b.cls[x]];
+				const int k = pk_decode(cl.cls).k;
+				SaPkClassArgs &a = args[x];
+				if (!pk_arranged_levels(ctx, b.g, cl.chunk, share_host, a.lv)) {
+					ok = false;
+					break;
+				}
+				a.chunk = cl.chunk;
+				a.jlist = cl.d_jlist;
+				a.tprefix = cl.d_tprefix;
+				a.dense_off = world >= 1 ? cl.d_doff : nullptr;
+				a.ncols = cl.ncols;
+				a.npart = cl.npart;
+				a.k = k;
+				a.delta = pk_delta(ctx, b.g, k);
+				a.pk_base = pk_base(ctx, b.g, k);
+			}
+			if (!ok)
+				break;
+			/* walking order, per rank: the large full tiles class after class, then everything smaller -- the full tiles of
+			 * the small-tile classes and the partial tiles of all classes -- by decreasing work (rows x per-step weight) */
+			std::vector<uint32_t> ul;
+			b.ufirst.assign((size_t)nranks + 1, 0);
 			b.nlocal.assign((size_t)nranks, 0);
 			b.pairs.assign((size_t)nranks, 0);
 			b.cells.assign((size_t)nranks, 0);
-			for (int r = 0; r < nranks && ok; r++) {
-				int32_t ubase = 0;
+			struct Part {
+				int64_t work;
+				uint32_t code;
+			};
+			std::vector<Part> parts;
+			for (int r = 0; r < nranks; r++) {
+				parts.clear();
 				for (size_t x = 0; x < b.cls.size(); x++) {
 					const auto &cl = plan.classes[(size_t)b.cls[x]];
-					const int k = cl.cls - (b.g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
-					SaPkClassArgs &a = args[(size_t)r * b.cls.size() + x];
-					a.jlist = cl.d_jlist;
-					a.tprefix = cl.d_tprefix;
-					a.tlist = world >= 1 ? cl.d_tlist + cl.rank_first[(size_t)r] : nullptr;
-					a.dense_off = world >= 1 ? cl.d_doff : nullptr;
-					a.ncols = cl.ncols;
-					a.npart = cl.npart;
-					a.k = k;
-					a.delta = pk_delta(ctx, b.g, k);
-					a.pk_base = pk_base(ctx, b.g, k);
-					a.ubase = ubase;
-					const int64_t un = (int64_t)ubase + (world >= 1 ? cl.rank_first[(size_t)r + 1] - cl.rank_first[(size_t)r] : cl.ntiles);
-					if (un > INT32_MAX) {
-						sa_set_error("packed range too large for one launch; split it into smaller ranges");
-						ok = false;
-						break;
+					const int32_t nfull = cl.ntiles - cl.npart;
+					for (int32_t t = 0; t < cl.ntiles; t++) {
+						if (world >= 1 && cl.owner[(size_t)t] != r)
+							continue;
+						const uint32_t code = ((uint32_t)x << SA_PK_UTILE_BITS) | (uint32_t)t;
+						const int64_t full_rows = (int64_t)SA_PK_WPB * (64 / b.g) * cl.chunk;
+						if (t < nfull && !pk_decode(cl.cls).small)
+							ul.push_back(code);
+						else /* small full tiles and every partial tile: by decreasing work, after the large full tiles */
+							parts.push_back({ (t < nfull ? full_rows : (int64_t)cl.part_rows[(size_t)(t - nfull)]) * (args[x].k + 4), code });
 					}
-					ubase = (int32_t)un;
 					b.pairs[(size_t)r] += world >= 1 ? cl.rank_pairs[(size_t)r] : cl.pairs;
 					b.cells[(size_t)r] += world >= 1 ? cl.rank_cells[(size_t)r] : cl.cells;
 				}
-				b.nlocal[(size_t)r] = ubase;
+				std::stable_sort(parts.begin(), parts.end(), [](const Part &p, const Part &q) { return p.work > q.work; });
+				for (const Part &pt : parts)
+					ul.push_back(pt.code);
+				b.ufirst[(size_t)r + 1] = (int64_t)ul.size();
+				const int64_t n = b.ufirst[(size_t)r + 1] - b.ufirst[(size_t)r];
+				if (n > INT32_MAX) {
+					sa_set_error("packed range too large for one launch; split it into smaller ranges");
+					ok = false;
+					break;
+				}
+				b.nlocal[(size_t)r] = (int32_t)n;
 			}
 			if (ok) {
 				SA_HIP_CHECK(hipMalloc(&b.d_args, sizeof(SaPkClassArgs) * args.size()), ok = false);
 			}
 			if (ok) {
 				SA_HIP_CHECK(hipMemcpy(b.d_args, args.data(), sizeof(SaPkClassArgs) * args.size(), hipMemcpyHostToDevice), ok = false);
+			}
+			if (ok) {
+				SA_HIP_CHECK(hipMalloc(&b.d_ulist, sizeof(uint32_t) * std::max<size_t>(ul.size(), 1)), ok = false);
+			}
+			if (ok && !ul.empty()) {
+				SA_HIP_CHECK(hipMemcpy(b.d_ulist, ul.data(), sizeof(uint32_t) * ul.size(), hipMemcpyHostToDevice), ok = false);
 			}
 			if (!ok)
 				break;
@@ -1260,7 +1411,7 @@ static const char *const METHOD_TAG[] = { "nw", "ga", "sw" };
 
 /* share: world >= 1 runs the tiles of `rank` only and stores them densely (sa_ctx_align_share); 0: the whole range */
 static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16,
-			    int world = 0, int rank = 0);
+			    int world = 0, int rank = 0, int32_t *host_out = nullptr);
 
 extern "C" int sa_ctx_align_range(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream)
 {
@@ -1316,18 +1467,24 @@ static bool share_args_ok(sa_ctx *ctx, int64_t start, int64_t count, int world, 
 	return true;
 }
 
-extern "C" int64_t sa_ctx_share_elems(sa_ctx *ctx, int64_t start, int64_t count, int world)
+extern "C" void sa_ctx_leave_room(sa_ctx *ctx, int on)
+{
+	if (ctx)
+		ctx->leave_room = on != 0;
+}
+
+extern "C" int64_t sa_ctx_share_elems(sa_ctx *ctx, int64_t start, int64_t count, int world, int to_host)
 {
 	if (!share_args_ok(ctx, start, count, world, "sa_ctx_share_elems"))
 		return -1;
 	SA_HIP_CHECK(hipSetDevice(ctx->device), return -1);
-	if (!plan_build(ctx, start, count, world))
+	if (!plan_build(ctx, start, count, world, to_host != 0))
 		return -1;
 	return ctx->plan->share_elems;
 }
 
 extern "C" int sa_ctx_align_share(sa_ctx *ctx, int64_t start, int64_t count, int world, int rank, void *d_share, int elem16,
-				   void *stream)
+				   int32_t *host_packed, void *stream)
 {
 	if (!share_args_ok(ctx, start, count, world, "sa_ctx_align_share"))
 		return 1;
@@ -1339,11 +1496,23 @@ extern "C" int sa_ctx_align_share(sa_ctx *ctx, int64_t start, int64_t count, int
 		sa_set_error("sa_ctx_align_share: scores of this store and scoring are not provably within int16");
 		return 1;
 	}
-	return align_range_impl(ctx, start, count, static_cast<int32_t *>(d_share), stream, elem16 != 0, world, rank);
+	int32_t *host_dev = nullptr;
+	if (host_packed) { /* the kernels store through the device-visible alias of the page-locked matrix */
+		SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
+		void *dp = nullptr;
+		if (!host_range_is_pinned(host_packed + start) || !host_range_is_pinned(host_packed + start + count - 1) ||
+		    hipHostGetDevicePointer(&dp, host_packed + start, 0) != hipSuccess) {
+			(void)hipGetLastError();
+			sa_set_error("sa_ctx_align_share: the host matrix is not page-locked over the range (sa_hip_host_register)");
+			return 1;
+		}
+		host_dev = static_cast<int32_t *>(dp);
+	}
+	return align_range_impl(ctx, start, count, static_cast<int32_t *>(d_share), stream, elem16 != 0, world, rank, host_dev);
 }
 
-extern "C" int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, int world, const void *d_shares, int elem16,
-				    int32_t *d_packed, void *stream)
+extern "C" int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, int world, int to_host, const void *d_shares,
+				    int elem16, int32_t *d_packed, void *stream)
 {
 	if (!share_args_ok(ctx, start, count, world, "sa_ctx_place_shares"))
 		return 1;
@@ -1352,7 +1521,7 @@ extern "C" int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, in
 		return 1;
 	}
 	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
-	if (!plan_build(ctx, start, count, world))
+	if (!plan_build(ctx, start, count, world, to_host != 0))
 		return 1;
 	SA_HIP_CHECK(sa_launch_place(ctx->plan->d_segs, ctx->plan->nsegs, d_shares, elem16, d_packed, (hipStream_t)stream), return 1);
 	return 0;
@@ -1361,8 +1530,10 @@ extern "C" int sa_ctx_place_shares(sa_ctx *ctx, int64_t start, int64_t count, in
 /* Arranged row streams of one packed launch of the current plan (builds the copies it needs on first use).  Scores
  * stored straight into host memory must leave in row order: there a block is one tile; in device memory a block may
  * span several tiles (their stores scatter inside it). */
-static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool host_out, SaSysArgs &a)
+static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool host_out, SaArranged (&lv)[SA_PK_SORT_LEVELS])
 {
+	for (auto &x : lv)
+		x = SaArranged{};
 	if (ctx->env_no_sort)
 		return true;
 	const int ng = 64 / pk_g;
@@ -1378,14 +1549,14 @@ static bool pk_arranged_levels(sa_ctx *ctx, int pk_g, int32_t chunk_pk, bool hos
 		if (!arranged_store(ctx, ng, chunk_pk, block, &ar))
 			return false;
 		if (ar)
-			a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
+			lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
 	}
 	if (nl < SA_PK_SORT_LEVELS) { /* the tile itself as a block: its scores leave in row order */
 		const sa_ctx::Arranged *ar = nullptr;
 		if (!arranged_store(ctx, ng, chunk_pk, rows, &ar))
 			return false;
 		if (ar)
-			a.lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
+			lv[nl++] = { ar->d_codes, ar->d_off, ar->d_rowmap, ar->d_posmap, ar->block };
 	}
 	return true;
 }
@@ -1397,7 +1568,7 @@ static bool prepare_range(sa_ctx *ctx, int64_t start, int64_t count, bool host_o
 {
 	if (count <= 0)
 		return true;
-	if (!plan_build(ctx, start, count))
+	if (!plan_build(ctx, start, count, 0, host_out))
 		return false;
 	const bool was = ctx->out_is_host;
 	ctx->out_is_host = host_out;
@@ -1405,8 +1576,8 @@ static bool prepare_range(sa_ctx *ctx, int64_t start, int64_t count, bool host_o
 	for (const auto &cl : ctx->plan->classes) {
 		if (cl.cls < SA_PK_CLASS0)
 			continue;
-		SaSysArgs a{};
-		ok = pk_arranged_levels(ctx, cl.cls >= SA_PK16_CLASS0 ? 16 : 8, ctx->plan->chunk_pk, host_out, a);
+		SaArranged lv[SA_PK_SORT_LEVELS];
+		ok = pk_arranged_levels(ctx, pk_decode(cl.cls).g, cl.chunk, host_out, lv);
 		if (!ok)
 			break;
 	}
@@ -1415,7 +1586,7 @@ static bool prepare_range(sa_ctx *ctx, int64_t start, int64_t count, bool host_o
 }
 
 static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_scores, void *stream, bool out16,
-			    int world, int rank)
+			    int world, int rank, int32_t *host_out)
 {
 	if (!ctx || start < 0 || count < 0 || start + count > ctx->pairs || (!d_scores && count)) {
 		sa_set_error("sa_ctx_align_range: bad range [%lld,+%lld) of %lld pairs", (long long)start,
@@ -1426,9 +1597,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		return 0;
 	SA_HIP_CHECK(hipSetDevice(ctx->device), return 1);
 	hipStream_t s = (hipStream_t)stream;
-	if (!plan_build(ctx, start, count, world))
-		return 1;
 	const bool share = world >= 1;
+	if (!plan_build(ctx, start, count, world, share ? host_out != nullptr : ctx->out_is_host))
+		return 1;
 
 	auto timed_begin = [&](hipEvent_t &e0, hipEvent_t &e1) -> bool {
 		if (!ctx->timing)
@@ -1502,6 +1673,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		a.gap_g = ctx->sc.gap_pen;
 		a.gap_o = ctx->sc.gap_opn;
 		a.gap_e = ctx->sc.gap_ext;
+		a.host_out = host_out;
 		int32_t ntiles_here;
 		int64_t pairs_here, cells_here;
 		char name[96];
@@ -1510,16 +1682,18 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.q = ctx->sc.method == SA_METHOD_SW ? 0 : ctx->pk_q;
 			a.out_nt = ctx->out_is_host && !share ? 1 : 0;
 			a.pk_f16 = pb->f16;
-			if (!pk_arranged_levels(ctx, pb->g, ctx->plan->chunk_pk, ctx->out_is_host && !share, a))
-				return 1;
-			a.chunk = ctx->plan->chunk_pk;
-			a.pkc = pb->d_args + (size_t)rk * pb->cls.size();
+			a.chunk = ctx->plan->chunk_pk; /* (the kernel takes chunk and arranged copies of every tile from its class block) */
+			a.stagger = ctx->env_stagger;
+			a.pkc = pb->d_args;
+			a.ulist = pb->d_ulist + pb->ufirst[(size_t)rk];
 			a.npkc = (int32_t)pb->cls.size();
 			a.nlocal = ntiles_here = pb->nlocal[(size_t)rk];
 			pairs_here = pb->pairs[(size_t)rk];
 			cells_here = pb->cells[(size_t)rk];
 			a.counter = counters + 2 * (SA_PK_CLASS0 + it.bundle);
-			const int klo_seen = ctx->plan->classes[(size_t)pb->cls.back()].cls - (pb->g == 16 ? SA_PK16_CLASS0 : SA_PK_CLASS0);
+			int klo_seen = pb->kmax;
+			for (int ci : pb->cls)
+				klo_seen = std::min(klo_seen, pk_decode(ctx->plan->classes[(size_t)ci].cls).k);
 			/* template arguments as rocprofv3 prints them, then the classes this launch walks */
 			snprintf(name, sizeof(name), "sa_k_systolic_pk_bundle<%s,%d,%d,%s>[K%d-%d]", METHOD_TAG[ctx->sc.method], pb->g, pb->klo,
 				 pb->f16 ? "true" : "false", klo_seen, pb->kmax);
@@ -1567,17 +1741,22 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		/* diagnostics: SA_HIP_STAMPS=1 makes every launch synchronous and prints the main-loop
 		 * cycles per step and the shader clock the chip held (never enabled in timed runs) */
 		unsigned long long *d_stamps = nullptr;
-		const size_t nstamp = is_pk ? 1 : (size_t)clp->ntiles;
+		const size_t nstamp = is_pk ? (size_t)ntiles_here : (size_t)clp->ntiles; /* (packed bundle: 7 words per tile) */
+		const size_t stamp_words = is_pk ? 7 * nstamp : 3 * nstamp;
 		if (ctx->env_stamps) {
-			SA_HIP_CHECK(hipMalloc(&d_stamps, 3 * sizeof(unsigned long long) * nstamp), return 1);
-			SA_HIP_CHECK(hipMemset(d_stamps, 0, 3 * sizeof(unsigned long long) * nstamp), return 1);
+			SA_HIP_CHECK(hipMalloc(&d_stamps, sizeof(unsigned long long) * stamp_words), return 1);
+			SA_HIP_CHECK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * stamp_words), return 1);
 			a.stamps = d_stamps;
 		}
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
-		const int wgs = (int)std::min<int64_t>(is_pk ? ctx->persistent_wgs / 4 : is_long ? ctx->long_wgs : ctx->persistent_wgs,
-						       ntiles_here);
+		/* packed bundle: four workgroups per CU fill its LDS (4 x 39.9 KB at K = 13..16) and saturate the SIMDs (measured:
+		 * a grid of 4 per CU = 8 per CU; 3 per CU: NW -8 %, Gotoh -1 %).  leave_room: three per CU, so that kernels of other
+		 * streams -- an RCCL collective, the placement of the previous super-chunk -- find LDS and wave slots beside them
+		 * (beside four they wait for the launch to end: a 0.05 ms placement took 0.73 ms and held the next kernel up) */
+		const int pk_wgs = ctx->env_pk_wgs ? ctx->env_pk_wgs : ctx->persistent_wgs / 32 * (ctx->leave_room ? 3 : 4);
+		const int wgs = (int)std::min<int64_t>(is_pk ? pk_wgs : is_long ? ctx->long_wgs : ctx->persistent_wgs, ntiles_here);
 		if (is_pk) {
 			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pb->g, pb->klo, pb->f16, a, wgs,
 							   (unsigned)sa_pk_lds_bytes(pb->g, pb->kmax), s), return 1);
@@ -1585,13 +1764,44 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cls, a, wgs, s), return 1);
 		}
 		if (d_stamps) {
-			std::vector<unsigned long long> h(3 * nstamp);
+			std::vector<unsigned long long> h(stamp_words);
 			SA_HIP_CHECK(hipStreamSynchronize(s), return 1);
 			SA_HIP_CHECK(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost), return 1);
 			(void)hipFree(d_stamps);
-			if (is_pk) { /* packed kernels: totals in the first triple: wave-steps executed, stream rows (8 per wave-step at best), wave-tiles */
-				fprintf(stderr, "[stamps] %s: %llu wave-tiles, %.0f steps per wave-tile, %.3f executed step slots per stream row (1.0 = no bubbles)\n",
-					name, h[2], (double)h[0] / (double)h[2], (double)h[0] * (64 / pb->g) / (double)h[1]);
+			if (is_pk) {
+				/* packed bundle: when every tile ran (100 MHz ticks) -> makespan, busy time, and how many workgroups were
+				 * working in each twentieth of the launch: ramp, plateau and tail at a glance */
+				unsigned long long t_lo = ~0ull, t_hi = 0;
+				double busy = 0;
+				for (size_t k = 0; k < nstamp; k++) {
+					t_lo = std::min(t_lo, h[3 * k]);
+					t_hi = std::max(t_hi, h[3 * k + 1]);
+					busy += (double)(h[3 * k + 1] - h[3 * k]);
+				}
+				const double span = (double)(t_hi - t_lo);
+				constexpr int BINS = 20;
+				double act[BINS] = {};
+				for (size_t k = 0; k < nstamp; k++) {
+					const double a0 = (double)(h[3 * k] - t_lo) / span * BINS, a1 = (double)(h[3 * k + 1] - t_lo) / span * BINS;
+					for (int b = (int)a0; b < BINS && b <= (int)a1; b++)
+						act[b] += std::min(a1, (double)b + 1) - std::max(a0, (double)b);
+				}
+				double clocks = 0, pro = 0, loop = 0, epi = 0, steps = 0;
+				for (size_t k = 0; k < nstamp; k++) {
+					const unsigned long long c0 = h[3 * k + 2], c1 = h[3 * nstamp + 3 * k], c2 = h[3 * nstamp + 3 * k + 1], c3 = h[6 * nstamp + k];
+					clocks += (double)(c3 - c0);
+					pro += (double)(c1 - c0);
+					loop += (double)(c2 - c1);
+					epi += (double)(c3 - c2);
+					steps += (double)h[3 * nstamp + 3 * k + 2];
+				}
+				fprintf(stderr, "[stamps] per tile: prologue %.0f clocks, main loop %.0f (%.0f steps, %.1f clocks per step), epilogue %.0f\n",
+					pro / (double)nstamp, loop / (double)nstamp, steps / (double)nstamp, loop / steps, epi / (double)nstamp);
+				fprintf(stderr, "[stamps] %s: %zu tiles, makespan %.1f us, mean tile %.1f us = %.0f shader clocks (%.0f MHz), mean active workgroups %.0f; active per 5%% of the launch:",
+					name, nstamp, span / 100.0, busy / (double)nstamp / 100.0, clocks / (double)nstamp, clocks / busy * 100.0, busy / span);
+				for (int b = 0; b < BINS; b++)
+					fprintf(stderr, " %.0f", act[b]);
+				fprintf(stderr, "\n");
 			} else {
 				double cyc = 0, rt = 0, steps = 0;
 				for (size_t k = 0; k < nstamp; k++) {
@@ -1639,6 +1849,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 		a.count = run.second;
 		a.out = out16 ? reinterpret_cast<int32_t *>(reinterpret_cast<int16_t *>(d_scores) + out_at) : d_scores + out_at;
 		a.out16 = out16 ? 1 : 0;
+		a.host_out = host_out ? host_out + (run.first - start) : nullptr;
 		a.scratch = ctx->d_scratch;
 		a.scratch_stride = ctx->scratch_stride;
 		const int blocks = (int)std::min<int64_t>(ctx->generic_blocks, (run.second + 3) / 4);
@@ -1782,16 +1993,6 @@ void host_scatter_full(int32_t *matrix, size_t dim, const int32_t *slice, int64_
 	}
 }
 
-/* is [p, p+bytes) already page-locked and known to the HIP runtime (hipHostMalloc / hipHostRegister)? */
-bool host_range_is_pinned(const void *p)
-{
-	hipPointerAttribute_t attr;
-	if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
-		(void)hipGetLastError();
-		return false;
-	}
-	return attr.type == hipMemoryTypeHost;
-}
 
 /* MemAvailable of the host: a destination larger than half of it (a file-backed matrix, src/io/output.c:36) is not
  * page-locked, its copies are staged by the runtime instead */
@@ -2054,7 +2255,8 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 	 * coalesced 128-byte runs leave the chip as posted PCIe writes while the next tiles compute -- ~6 GB/s at
 	 * cfg 2's rate against a link that moves ~50 -- so there is no copy pass, no batching and a single launch tail. */
 	int32_t *direct = nullptr;
-	if (out.matrix && out.triangular && !ctx->env_no_direct && host_range_is_pinned(out.matrix + start)) {
+	if (out.matrix && out.triangular && !ctx->env_no_direct && host_range_is_pinned(out.matrix + start) &&
+	    host_range_is_pinned(out.matrix + start + total - 1)) {
 		void *dp = nullptr;
 		if (hipHostGetDevicePointer(&dp, out.matrix + start, 0) == hipSuccess)
 			direct = static_cast<int32_t *>(dp);

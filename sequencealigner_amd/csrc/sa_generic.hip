@@ -13,6 +13,7 @@
  * It is the fallback of the systolic streaming kernels (sa_systolic.hip), which
  * need bounded scores and len <= their column budget; this one does not.
  */
+#include <algorithm>
 #include "sa_internal.h"
 
 namespace {
@@ -161,6 +162,8 @@ __global__ __launch_bounds__(256) void sa_k_pair_per_wave(SaGenericArgs A)
 				reinterpret_cast<int16_t *>(A.out)[q] = (int16_t)score;
 			else
 				A.out[q] = score;
+			if (A.host_out)
+				__builtin_nontemporal_store(score, &A.host_out[q]);
 		}
 	}
 }
@@ -293,16 +296,48 @@ hipError_t sa_launch_expand_full(const int32_t *packed, int32_t *full, int32_t n
  * contiguous, writes land inside one arranged block of the column (<= 2048 rows = an 8 KB window the L2 merges), in row
  * order where the tile streamed in store order. */
 template <typename T>
-__global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__ segs, const T *__restrict__ shares,
+__global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__ segs, int32_t nsegs, const T *__restrict__ shares,
 						   int32_t *__restrict__ packed)
 {
-	const SaPlaceSeg sg = segs[blockIdx.x];
-	const T *src = shares + sg.src;
-	int32_t *dst = packed + sg.dst;
-	for (int32_t p = threadIdx.x; p < sg.count; p += 256) {
-		const int32_t r = sg.rowmap ? sg.rowmap[sg.pos0 + p] : sg.pos0 + p;
-		if (r >= sg.ia && r < sg.ib)
-			dst[r] = (int32_t)src[p];
+	/* One WAVE per run and pass (a run is at most a tile's rows; a workgroup per run was 240 000 workgroups of one
+	 * iteration each for cfg 2 at 8 ranks -- 0.45 ms of dispatch).  A tile that is its own arranged block holds a
+	 * permutation of the rows [pos0, pos0 + count): it is un-permuted in LDS and leaves as contiguous 16-byte stores --
+	 * scattered 4-byte stores made the L2 write partial lines (1.2 TB/s for the whole pass). */
+	constexpr int OWN_MAX = 1024;
+	__shared__ int32_t s_rows[4][OWN_MAX];
+	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	typedef int32_t i32x4 __attribute__((ext_vector_type(4), aligned(4)));
+	for (int32_t base = (int32_t)blockIdx.x * 4; base < nsegs; base += (int32_t)gridDim.x * 4) { /* (uniform trip count) */
+		const int32_t k = base + w;
+		SaPlaceSeg sg{};
+		if (k < nsegs)
+			sg = segs[k];
+		const T *src = shares + sg.src;
+		int32_t *dst = packed + sg.dst;
+		const bool own = sg.rowmap && (sg.flags & 1) && sg.count <= OWN_MAX;
+		if (own)
+			for (int32_t p = lane; p < sg.count; p += 64)
+				s_rows[w][sg.rowmap[sg.pos0 + p] - sg.pos0] = (int32_t)src[p];
+		__syncthreads();
+		if (own) {
+			for (int32_t q = 4 * lane; q < sg.count; q += 256) {
+				const int32_t r = sg.pos0 + q;
+				if (r >= sg.ia && r + 4 <= sg.ib && q + 4 <= sg.count) {
+					*reinterpret_cast<i32x4 *>(dst + r) = *reinterpret_cast<const i32x4 *>(&s_rows[w][q]);
+				} else {
+					for (int e = 0; e < 4 && q + e < sg.count; e++)
+						if (r + e >= sg.ia && r + e < sg.ib)
+							dst[r + e] = s_rows[w][q + e];
+				}
+			}
+		} else {
+			for (int32_t p = lane; p < sg.count; p += 64) {
+				const int32_t r = sg.rowmap ? sg.rowmap[sg.pos0 + p] : sg.pos0 + p;
+				if (r >= sg.ia && r < sg.ib)
+					dst[r] = (int32_t)src[p];
+			}
+		}
+		__syncthreads();
 	}
 }
 
@@ -310,10 +345,11 @@ hipError_t sa_launch_place(const SaPlaceSeg *segs, int32_t nsegs, const void *sh
 {
 	if (nsegs <= 0)
 		return hipSuccess;
+	const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)nsegs + 3) / 4, 256 * 10); /* 16 KB of LDS each: 10 per CU */
 	if (elem16)
-		hipLaunchKernelGGL(sa_k_place<int16_t>, dim3((unsigned)nsegs), dim3(256), 0, s, segs, static_cast<const int16_t *>(shares), packed);
+		hipLaunchKernelGGL(sa_k_place<int16_t>, dim3(blocks), dim3(256), 0, s, segs, nsegs, static_cast<const int16_t *>(shares), packed);
 	else
-		hipLaunchKernelGGL(sa_k_place<int32_t>, dim3((unsigned)nsegs), dim3(256), 0, s, segs, static_cast<const int32_t *>(shares), packed);
+		hipLaunchKernelGGL(sa_k_place<int32_t>, dim3(blocks), dim3(256), 0, s, segs, nsegs, static_cast<const int32_t *>(shares), packed);
 	return hipGetLastError();
 }
 

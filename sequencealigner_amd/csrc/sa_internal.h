@@ -34,6 +34,7 @@ struct SaSeqStore {
 
 struct SaGenericArgs {
 	SaSeqStore st;
+	int32_t *host_out;            /* != nullptr: the scores also go to host_out[q] (s32), see SaSysArgs::host_out */
 	const int32_t *sub;           /* s32[24*24] substitution matrix in HBM                  */
 	int32_t gap_pen, gap_opn, gap_ext;
 	int64_t start, count;         /* packed pair range                                      */
@@ -98,24 +99,39 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 /* class index space of a plan: [0, SA_SYS_NCLASSES) s32 classes, SA_SYS_CLASS_LONG, then SA_PK_CLASS0 + K (8-lane groups),
  * then SA_PK16_CLASS0 + K (16-lane groups) */
 enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 + SA_PK_KMAX + 1,
-	     SA_PLAN_NCLASSES = SA_PK16_CLASS0 + SA_PK16_KMAX + 1 };
+	     SA_PK_CLASSES_END = SA_PK16_CLASS0 + SA_PK16_KMAX + 1,
+	     /* ... and every packed class once more, + SA_PK_SMALL: the columns of the class that a plan runs in its SMALL tiles (the
+	      * lowest columns of the range, put at the end of the launch so that it tapers off: sa_driver.hip plan_build) */
+	     SA_PK_SMALL = SA_PK_CLASSES_END - SA_PK_CLASS0,
+	     SA_PLAN_NCLASSES = SA_PK_CLASSES_END + SA_PK_SMALL };
 
 /* The packed kernels are launched as BUNDLES: one persistent kernel (sa_k_systolic_pk_bundle<METHOD, G, KLO, F16>) walks
- * the tiles of up to SA_PK_BUNDLE consecutive K classes, class after class -- one launch on the caller's stream, one tail
+ * the tiles of up to SA_PK_BUNDLE consecutive K classes -- one launch on the caller's stream, one tail
  * for the whole range instead of one per class, and no cross-stream fork / join (six class launches on side streams ran
  * as two rounds of three on the runtime's hardware queues and cost ~70 us of events and barriers per range:
  * profiles/r03a_*).  8-lane groups: KLO = 1, 9, 17; 16-lane groups: KLO = 13, 21, 29, 37.  The registers of a bundle are
  * those of its largest K (K <= 16: <= 127 VGPRs for every method, four waves per SIMD as before). */
 #define SA_PK_BUNDLE 8
-struct SaPkClassArgs { /* one class of a bundle launch, in device memory (share plans: one array per rank) */
+struct SaArranged { /* one arranged copy of the row store (sa_driver.hip: arranged_store); rows = 0: none */
+	const uint8_t *codes;
+	const int32_t *off;    /* num+1 offsets into codes by position */
+	const int32_t *rowmap; /* position -> row                      */
+	const int32_t *posmap; /* row -> position                      */
+	int32_t rows;          /* sequences per arranged block         */
+};
+struct SaPkClassArgs { /* one class of a bundle launch, in device memory */
 	const int32_t *jlist;     /* columns (ascending) of the class                                        */
 	const int32_t *tprefix;   /* full tiles before each column pair, then the pairs of the partial tiles */
-	const int32_t *tlist;     /* share plans: this rank's tiles of the class; nullptr: all of them       */
 	const int64_t *dense_off; /* share plans: element offset of tile t in its owner's dense share        */
 	int32_t ncols, npart, k;
 	int32_t delta, pk_base;
-	int32_t ubase;            /* launch-tile index of the class's first tile (classes are walked in order) */
+	int32_t chunk;            /* sequences per row stream of a full tile of this class (SaSysArgs::chunk)  */
+	SaArranged lv[SA_PK_SORT_LEVELS]; /* arranged copies of the row store for this tile shape              */
 };
+/* a bundle launch walks ulist[0 .. nlocal): (class of the launch << SA_PK_UTILE_BITS) | tile of the class -- the full
+ * tiles class after class (largest K first), then the partial tiles of ALL classes by decreasing size, so that the
+ * launch tapers off on its cheapest tiles; share plans: the tiles of one rank in that order */
+#define SA_PK_UTILE_BITS 28
 /* LDS of a packed workgroup: scores leaving the pipeline, token rings, then the profile of the column pair (the only
  * part that depends on K): a launch asks for the bytes of its largest K as dynamic LDS */
 __host__ __device__ constexpr int sa_pk_lds_fixed(int g) { return 1664 * (64 / g); }
@@ -141,13 +157,7 @@ struct SaSysArgs {
 	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
 	int32_t pk_base;         /* packed kernels: the constant baseline BASE                                     */
 	/* packed kernels: arranged copies of the store (sa_driver.hip: arranged_store), largest block first; rows = 0: none */
-	struct Arranged {
-		const uint8_t *codes;
-		const int32_t *off;    /* num+1 offsets into codes by position */
-		const int32_t *rowmap; /* position -> row                      */
-		const int32_t *posmap; /* row -> position                      */
-		int32_t rows;          /* sequences per arranged block         */
-	} lv[SA_PK_SORT_LEVELS];
+	const SaArranged *lvp;   /* packed kernels: the SA_PK_SORT_LEVELS arranged copies offered to the class of the tile being run */
 	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
 	int32_t out_nt;          /* packed kernels: out is host memory, store non-temporally                        */
 	int32_t pk_f16;          /* packed kernels: the class's values fit SA_PK_F16_MAX (three-way f16 maxima)     */
@@ -157,11 +167,16 @@ struct SaSysArgs {
 	 * tlist == nullptr: every tile of the list; dense_off == nullptr: packed order, out[p - start]. */
 	const int32_t *tlist;
 	const int64_t *dense_off;
+	int32_t *host_out;        /* dense shares only: page-locked packed host matrix (device-visible address of element
+	                           * `start`) that receives the same scores in packed order, or nullptr          */
 	int32_t nlocal;
-	const SaPkClassArgs *pkc; /* packed bundle launch: its classes in walking order; nlocal = tiles of the whole launch */
+	const SaPkClassArgs *pkc; /* packed bundle launch: its classes; nlocal = tiles of the whole launch */
+	const uint32_t *ulist;    /* ... and its tiles in walking order (SA_PK_UTILE_BITS)                  */
 	int32_t npkc;
 	unsigned *counter;       /* [0] next unclaimed tile of this launch, [1] workgroups that have left; both zero before
 	                          * the launch and put back to zero by its last workgroup                           */
+	int32_t stagger;            /* packed bundle: sleep periods (8128 clocks) per wave slot before the first tile      */
+	int32_t stamp_u;            /* diagnostics: launch-tile index of the tile being run (packed bundle)                */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
 	                             * steps} of the main loop; nullptr in production                        */
 };
@@ -196,6 +211,8 @@ struct SaPlaceSeg {
 	int64_t dst;           /* tri(j) - start of the placed range; generic runs: run start - start */
 	const int32_t *rowmap; /* arranged tiles: position -> row                                     */
 	int32_t count, pos0, ia, ib;
+	int32_t flags;         /* bit 0: the run's rows are a permutation of [pos0, pos0 + count)     */
+	int32_t pad_;
 };
 hipError_t sa_launch_place(const SaPlaceSeg *segs, int32_t nsegs, const void *shares, int elem16, int32_t *packed, hipStream_t s);
 

@@ -166,33 +166,36 @@ def column_chunks(n: int, chunks: int, ratio: float = 3.0) -> list[tuple[int, in
     return out
 
 
-def host_piece(start: int, count: int, world: int, rank: int) -> tuple[int, int]:
-    """packed range [lo, hi) of a super-chunk that `rank` copies to ITS host buffer (every rank drives its own PCIe link;
-    on one node the pieces make up the matrix)"""
-    per = (count + world - 1) // world
-    lo = min(count, rank * per)
-    return start + lo, start + min(count, lo + per)
-
-
 class HipShares:
     """The device side of TiledGatherStep: sa_ctx_share_elems / sa_ctx_align_share / sa_ctx_place_shares on torch
-    tensors and streams."""
+    tensors and streams.  `host`: a binding.PinnedMatrix holding the WHOLE packed host matrix (private, or one shared
+    mapping all ranks attach), or None for no host delivery."""
 
     device = "cuda"
 
-    def __init__(self, ctx, use16: bool):
+    def __init__(self, ctx, use16: bool, host=None):
         import torch
-        self.torch, self.ctx, self.use16 = torch, ctx, bool(use16)
+        self.torch, self.ctx, self.use16, self.host = torch, ctx, bool(use16), host
         self.dtype = torch.int16 if use16 else torch.int32
 
-    def share_elems(self, start, count, world):
-        return self.ctx.share_elems(start, count, world)
+    @property
+    def to_host(self):
+        return self.host is not None
 
-    def align_share(self, start, count, world, rank, share, stream):
-        self.ctx.align_share(start, count, world, rank, share.data_ptr(), self.use16, stream.cuda_stream)
+    def share_elems(self, start, count, world):
+        return self.ctx.share_elems(start, count, world, self.to_host)
+
+    def align_share(self, start, count, world, rank, share, stream, leave_room=False):
+        self.ctx.leave_room(leave_room)
+        try:
+            self.ctx.align_share(start, count, world, rank, share.data_ptr(), self.use16, stream.cuda_stream,
+                                 self.host.ptr if self.to_host else 0)
+        finally:
+            self.ctx.leave_room(False)
 
     def place(self, start, count, world, shares, packed_range, stream):
-        self.ctx.place_shares(start, count, world, shares.data_ptr(), self.use16, packed_range.data_ptr(), stream.cuda_stream)
+        self.ctx.place_shares(start, count, world, shares.data_ptr(), self.use16, packed_range.data_ptr(), stream.cuda_stream,
+                              self.to_host)
 
 
 class _Inline:
@@ -205,25 +208,37 @@ class _Inline:
         pass
 
 
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
 class TiledGatherStep:
     """One whole-job step on `world` ranks with tile-interleaved shares (see the module docstring).
 
     Per super-chunk c (geometric column ranges; streams of this rank, nothing below synchronises the host):
-      compute[c]  sa_ctx_align_share: the kernels of MY tiles of super-chunk c      -> my dense share (int16 or s32)
-      comm        all_gather_into_tensor(shares[c], my share)                        -> every GPU holds all shares
-      deliver     sa_ctx_place_shares: widen + place into packed[start_c ...];
-                  device->host copy of this rank's 1/world piece of the finished super-chunk into pinned memory
+      compute     sa_ctx_align_share: the kernels of MY tiles of super-chunk c -> my dense share (int16 or s32) (from the
+                  second super-chunk on with sa_ctx_leave_room: the collective of the one before needs LDS beside them), and,
+                  when the backend has a host matrix, the same scores straight into it in packed order (every rank
+                  stores what it computed: together the ranks fill the host matrix exactly once -- no copy pass,
+                  no waiting for the gather; the reference's device->host copies, seqalign_cuda.c:266-283)
+      comm        all_gather_into_tensor(shares[c], my share)                   -> every GPU holds all shares
+      deliver     sa_ctx_place_shares: widen + place into packed[start_c ...]   -> the packed s32 vector on every GPU
     The step returns with the main stream waiting for everything: an event on the main stream marks "packed s32
-    vector complete on every GPU AND this rank's piece of it on the host".
+    vector complete on every GPU AND this rank's scores in the host matrix".
 
     `dist=None` with world > 1 emulates the other ranks on this device (their shares are computed here too, in place of
-    the all-gather): tests and one-GPU rehearsals."""
+    the all-gather): tests.  `solo=True`: only this rank's share is computed and nothing is gathered (the other shares
+    hold stale data): timing rehearsals of one rank's step on one GPU."""
 
-    def __init__(self, backend, n: int, world: int, rank: int, chunks: int, dist=None, to_host: bool = True):
+    def __init__(self, backend, n: int, world: int, rank: int, chunks: int, dist=None, solo: bool = False):
         import torch
 
         self.torch, self.be, self.dist = torch, backend, dist
-        self.world, self.rank = world, rank
+        self.world, self.rank, self.solo = world, rank, bool(solo)
         self.pairs = tri(n)
         self.ranges = column_chunks(n, chunks)
         self.chunks = len(self.ranges)
@@ -231,73 +246,48 @@ class TiledGatherStep:
         self.elems = [backend.share_elems(lo, cnt, world) for lo, cnt in self.ranges]
         self.shares = [torch.zeros(world * e, dtype=backend.dtype, device=backend.device) for e in self.elems]
         self.packed = torch.zeros(self.pairs, dtype=torch.int32, device=backend.device)
-        self.to_host = bool(to_host)
-        self.pieces = [host_piece(lo, cnt, world, rank) for lo, cnt in self.ranges]
-        self.host_off = [0]
-        for lo, hi in self.pieces:
-            self.host_off.append(self.host_off[-1] + hi - lo)
-        self.host = None
-        if self.to_host:
-            self.host = torch.zeros(max(self.host_off[-1], 1), dtype=torch.int32)
-            if cuda:
-                self.host = self.host.pin_memory()
         if cuda:
             self.main = torch.cuda.current_stream()
-            self.compute = [torch.cuda.Stream() for _ in range(self.chunks)]
+            # ONE compute stream: the super-chunks' kernels run one after the other (on streams of their own they would all
+            # start together and finish together -- nothing for the gather of the first one to hide behind)
+            self.compute = torch.cuda.Stream()
             self.comm, self.deliver = torch.cuda.Stream(), torch.cuda.Stream()
             self._event = torch.cuda.Event
         else:
-            self.main = _Inline()
-            self.compute = [_Inline() for _ in range(self.chunks)]
-            self.comm, self.deliver = _Inline(), _Inline()
+            self.main = self.compute = self.comm = self.deliver = _Inline()
             self._event = _Inline
 
     def my_share(self, c: int, r: int | None = None):
         r = self.rank if r is None else r
         return self.shares[c][r * self.elems[c]:(r + 1) * self.elems[c]]
 
-    def host_ranges(self):
-        """[(packed_lo, packed_hi, host_offset)] of what this rank delivers"""
-        return [(lo, hi, off) for (lo, hi), off in zip(self.pieces, self.host_off)]
-
     def __call__(self):
         torch, dist, be = self.torch, self.dist, self.be
         cuda = be.device == "cuda"
         start = self._event()
         start.record(self.main)
+        cs = self.compute
+        cs.wait_event(start)  # ordered after the previous step
         for c, (lo, cnt) in enumerate(self.ranges):
-            cs = self.compute[c]
-            cs.wait_event(start)  # ordered after the previous step
-            ranks = [self.rank] if (dist is not None or self.world == 1) else range(self.world)
+            ranks = [self.rank] if (dist is not None or self.world == 1 or self.solo) else range(self.world)
             for r in ranks:  # (more than one only when the other ranks are emulated here)
-                be.align_share(lo, cnt, self.world, r, self.my_share(c, r), cs)
+                # from the second super-chunk on, the gather and the placement of the one before run beside these kernels
+                be.align_share(lo, cnt, self.world, r, self.my_share(c, r), cs, leave_room=c > 0)
             done = self._event()
             done.record(cs)
             gathered = done
             if dist is not None and self.world > 1:
                 self.comm.wait_event(done)
-                ctxm = torch.cuda.stream(self.comm) if cuda else _null()
-                with ctxm:
+                with (torch.cuda.stream(self.comm) if cuda else _null()):
                     # (the process group moves bytes; int16 is not among its dtypes, uint8 is)
                     dist.all_gather_into_tensor(self.shares[c].view(torch.uint8), self.my_share(c).view(torch.uint8))
                 gathered = self._event()
                 gathered.record(self.comm)
             self.deliver.wait_event(gathered)
             be.place(lo, cnt, self.world, self.shares[c], self.packed[lo:lo + cnt], self.deliver)
-            if self.to_host:
-                plo, phi = self.pieces[c]
-                if phi > plo:
-                    ctxm = torch.cuda.stream(self.deliver) if cuda else _null()
-                    with ctxm:
-                        self.host[self.host_off[c]:self.host_off[c] + phi - plo].copy_(self.packed[plo:phi], non_blocking=True)
         fin = self._event()
         fin.record(self.deliver)
         self.main.wait_event(fin)
-
-
-class _null:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
+        last = self._event()
+        last.record(cs)  # (the host stores of the last kernels are complete when the kernels are)
+        self.main.wait_event(last)

@@ -1,3 +1,4 @@
+import os
 import pathlib
 import sys
 
@@ -6,6 +7,10 @@ import pytest
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
+
+
+# a SIGABRT raised anywhere in the test process (runtime, allocator, library) leaves its C backtrace here
+os.environ.setdefault("SA_HIP_ABORT_TRACE", str(ROOT / "gpurun_out" / "abort_backtrace.txt"))
 
 
 def pytest_configure(config):

@@ -61,14 +61,20 @@ def test_placed_shares_match_reference_digests(name, world, sa):
     scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
     with sa.Context(store, scoring, 0) as ctx:
         assert ctx.scores_fit16
-        e = ctx.share_elems(0, store.pairs, world)
-        shares = torch.zeros(world * e, dtype=torch.int16, device="cuda")
-        packed = torch.zeros(store.pairs, dtype=torch.int32, device="cuda")
-        s = torch.cuda.current_stream().cuda_stream
-        for r in range(world):
-            ctx.align_share(0, store.pairs, world, r, shares.data_ptr() + 2 * r * e, True, s)
-        ctx.place_shares(0, store.pairs, world, shares.data_ptr(), True, packed.data_ptr(), s)
-        torch.cuda.synchronize()
-        got = packed.cpu().numpy()
+        host = sa.PinnedMatrix(store.pairs)
+        try:
+            e = ctx.share_elems(0, store.pairs, world, True)
+            shares = torch.zeros(world * e, dtype=torch.int16, device="cuda")
+            packed = torch.zeros(store.pairs, dtype=torch.int32, device="cuda")
+            s = torch.cuda.current_stream().cuda_stream
+            for r in range(world):
+                ctx.align_share(0, store.pairs, world, r, shares.data_ptr() + 2 * r * e, True, s, host.ptr)
+            ctx.place_shares(0, store.pairs, world, shares.data_ptr(), True, packed.data_ptr(), s, True)
+            torch.cuda.synchronize()
+            got = packed.cpu().numpy()
+            got_host = host.array.copy()
+        finally:
+            host.close()
     assert int(got.sum(dtype=np.int64)) == meta["total_sum"]
     _compare(column_digests(got, store.num), want, f"{name} placed shares, world {world}")
+    _compare(column_digests(got_host, store.num), want, f"{name} host matrix filled by {world} ranks' direct stores")

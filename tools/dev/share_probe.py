@@ -29,14 +29,23 @@ j = store.num - 1
 lo = j * (j - 1) // 2
 t_small = bench(lambda: ctx.align_range(lo, j, full.data_ptr(), s), 50)
 print(f"last column only ({j} pairs): {t_small*1e3:.3f} ms per call")
-e = ctx.share_elems(0, store.pairs, world)
+e = ctx.share_elems(0, store.pairs, world, True)
+host = sa.PinnedMatrix(store.pairs)
 buf = torch.empty(e, dtype=torch.int16, device="cuda")
 for rank in (0, world - 1):
-    t = bench(lambda: ctx.align_share(0, store.pairs, world, rank, buf.data_ptr(), True, s))
+    t = bench(lambda: ctx.align_share(0, store.pairs, world, rank, buf.data_ptr(), True, s, host.ptr))
     print(f"share of rank {rank}/{world}: {t*1e3:.3f} ms = {t_full/world/t*100:.1f} % of ideal; share_elems {e} ({e*world/store.pairs:.4f} x pairs)")
 # all ranks' shares back to back on one GPU = the whole job in shares
 def all_shares():
     for r in range(world):
-        ctx.align_share(0, store.pairs, world, r, buf.data_ptr(), True, s)
+        ctx.align_share(0, store.pairs, world, r, buf.data_ptr(), True, s, host.ptr)
 t = bench(all_shares, 5)
 print(f"all {world} shares back to back: {t*1e3:.3f} ms ({t/world*1e3:.3f} per share)")
+
+# the whole step of one rank without the fabric: my kernels, place of all shares, host copy of my piece (solo rehearsal)
+from sequencealigner_amd.distributed import HipShares, TiledGatherStep
+for chunks in (1, 2, 3):
+    step = TiledGatherStep(HipShares(ctx, True, host), store.num, world, world - 1, chunks, None, solo=True)
+    t = bench(step)
+    print(f"solo step of rank {world-1}/{world}, {chunks} super-chunks (kernels + place + host copy, no all-gather): {t*1e3:.3f} ms = {t_full/world/t*100:.1f} % of ideal")
+    del step

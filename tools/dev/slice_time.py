@@ -27,6 +27,7 @@ for _ in range(10): whole()
 torch.cuda.synchronize(); t_full = (time.perf_counter() - t0) / 10
 print(f"{cfgname} whole range on one GPU: {t_full*1e3:.3f} ms  -> ideal share at world {world}: {t_full/world*1e3:.3f} ms")
 ranges = column_chunks(store.num, chunks)
+host = sa.PinnedMatrix(store.pairs)
 for rank in (0, world // 2, world - 1):
     if mode == "range":
         sched = ChunkedGather(store.pairs, world, rank, chunks)
@@ -36,10 +37,10 @@ for rank in (0, world // 2, world - 1):
                 lo, hi = sched.slice_range(c)
                 ctx.align_range(lo, hi - lo, buf.data_ptr(), s)
     else:
-        bufs = [torch.empty(ctx.share_elems(lo, cnt, world), dtype=torch.int16, device="cuda") for lo, cnt in ranges]
+        bufs = [torch.empty(ctx.share_elems(lo, cnt, world, True), dtype=torch.int16, device="cuda") for lo, cnt in ranges]
         def step():
             for (lo, cnt), b in zip(ranges, bufs):
-                ctx.align_share(lo, cnt, world, rank, b.data_ptr(), True, s)
+                ctx.align_share(lo, cnt, world, rank, b.data_ptr(), True, s, host.ptr)
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
