@@ -501,7 +501,7 @@ static void pk_setup(sa_ctx *ctx)
 			if (top > 65535)
 				break;
 			ctx->pk16_kmax = k;
-			if (top <= SA_PK_F16_MAX)
+			if (top <= SA_PK_F16_MAX && k <= SA_PK16_F16_KMAX)
 				ctx->pk16_f16_kmax = k;
 		}
 }
@@ -977,13 +977,13 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 		if (ctx->env_chunk)
 			cpk = ctx->env_chunk;
 		plan.chunk_pk = cpk;
-		/* Two tile sizes for a launch that gives a workgroup slot fewer than ~24 tiles (one rank's share of a multi-GPU
+		/* Two tile sizes for a launch that gives a workgroup slot fewer than 16 tiles (one rank's share of a multi-GPU
 		 * run; a super-chunk): when the tiles run out the slots finish their last ones over a whole tile's duration, and
 		 * only work in small units can fill that triangle.  So the bulk runs in tiles as large as leave >= 2.5 per slot,
 		 * and the lowest columns of the range -- a fifth of its pairs -- in tiles a quarter of that size, which the
 		 * launch order puts last (small tiles cost more per row, +5 % at a quarter of the full size, so not everywhere). */
 		const int64_t slots = (int64_t)ctx->persistent_wgs / 8;
-		if (!ctx->env_chunk && !getenv("SA_HIP_ONE_TILE_SIZE") && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < 24 * slots) {
+		if (!ctx->env_chunk && !getenv("SA_HIP_ONE_TILE_SIZE") && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < 16 * slots) {
 			int32_t big = SA_SYS_CHUNK;
 			while (big > 16 && 2 * mine / ((int64_t)2 * SA_PK_WPB * 8 * big) < 5 * slots)
 				big >>= 1;

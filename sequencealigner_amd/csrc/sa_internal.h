@@ -88,14 +88,19 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 #define SA_PK_K_LIST(X) \
 	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
 	X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24)
-/* ... and 16-lane groups with K = 13..40 columns per lane for 193..640 columns (one group per DPP row: the 16 lanes of a
- * ds_read_b128 phase are 16 distinct slots, so one profile copy is conflict-free; K = 40: a 65 KB profile and the last
- * profile-row offset that still fits the u16 token) */
+/* ... and 16-lane groups with K = 13..64 columns per lane for 193..1024 columns (one group per DPP row: the 16 lanes of a
+ * ds_read_b128 phase are 16 distinct slots, so one profile copy is conflict-free).  Up to K = 40 the token of a row is
+ * its byte offset in the profile (u16); beyond, the offset in units of 256 bytes -- one shift-add instead of one add
+ * per step.  K = 64: a 106 KB profile, one workgroup per CU.  The three-way (f16-ordered) form exists up to
+ * SA_PK16_F16_KMAX: past ~800 columns no common scoring keeps two frames inside 0x7bff. */
 #define SA_PK_K16_MIN 13
-#define SA_PK16_KMAX 40
+#define SA_PK16_KMAX 64
+#define SA_PK16_F16_KMAX 52
 #define SA_PK_K16_LIST(X) \
 	X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23) X(24) X(25) X(26) \
-	X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40)
+	X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39) X(40) \
+	X(41) X(42) X(43) X(44) X(45) X(46) X(47) X(48) X(49) X(50) X(51) X(52) X(53) X(54) \
+	X(55) X(56) X(57) X(58) X(59) X(60) X(61) X(62) X(63) X(64)
 /* class index space of a plan: [0, SA_SYS_NCLASSES) s32 classes, SA_SYS_CLASS_LONG, then SA_PK_CLASS0 + K (8-lane groups),
  * then SA_PK16_CLASS0 + K (16-lane groups) */
 enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 + SA_PK_KMAX + 1,
@@ -109,7 +114,7 @@ enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 +
  * the tiles of up to SA_PK_BUNDLE consecutive K classes -- one launch on the caller's stream, one tail
  * for the whole range instead of one per class, and no cross-stream fork / join (six class launches on side streams ran
  * as two rounds of three on the runtime's hardware queues and cost ~70 us of events and barriers per range:
- * profiles/r03a_*).  8-lane groups: KLO = 1, 9, 17; 16-lane groups: KLO = 13, 21, 29, 37.  The registers of a bundle are
+ * profiles/r03a_*).  8-lane groups: KLO = 1, 9, 17; 16-lane groups: KLO = 13, 21, ... 61.  The registers of a bundle are
  * those of its largest K (K <= 16: <= 127 VGPRs for every method, four waves per SIMD as before). */
 #define SA_PK_BUNDLE 8
 struct SaArranged { /* one arranged copy of the row store (sa_driver.hip: arranged_store); rows = 0: none */

@@ -11,5 +11,5 @@ for c in cfg2 cfg3 cfg4; do
 done
 python3 tools/make_traffic_json.py gpurun_out/prof_${T}_cfg2 $T cfg2
 python3 tools/make_traffic_json.py gpurun_out/prof_${T}_cfg3 $T cfg3
-python3 tools/make_traffic_json.py gpurun_out/prof_${T}_cfg4 $T cfg4 12000
+python3 tools/make_traffic_json.py gpurun_out/prof_${T}_cfg4 $T cfg4
 ls profiles | grep "^$T" | wc -l
