@@ -92,6 +92,7 @@ struct sa_ctx {
 	/* packed-u16 kernels (sa_systolic_pk.inc): column classes K = 1..pk_kmax run there (0: none), see pk_setup */
 	int pk_kmax = 0, pk16_kmax = 0; /* 8-lane groups: K = 1..pk_kmax; 16-lane groups: K = SA_PK_K16_MIN..pk16_kmax */
 	int pk16_f16_kmax = 0;          /* 16-lane groups: classes up to this K fit the f16 range (three-way maxima)      */
+	int pk_chunk_cap = SA_SYS_CHUNK; /* longest row stream (sequences) the packed classes may be given (SW: bounds the drift) */
 	int32_t pk_pconst = 0, pk_q = 0, pk_floor = 0; /* pk_floor: margin below the lowest legitimate value (part of BASE) */
 	int64_t pk_gain = 0, pk_slack = 0, pk_extra = 0;
 	/* arranged copies of the store for the packed kernels' row streams (arranged_store), one per tile shape */
@@ -444,6 +445,7 @@ static void pk_setup(sa_ctx *ctx)
 {
 	const sa_scoring &sc = ctx->sc;
 	ctx->pk_kmax = ctx->pk16_kmax = ctx->pk16_f16_kmax = 0;
+	ctx->pk_chunk_cap = SA_SYS_CHUNK;
 	if (!ctx->sys_ok || getenv("SA_HIP_NO_PK"))
 		return;
 	int64_t smax = INT32_MIN, smin = INT32_MAX;
@@ -464,7 +466,14 @@ static void pk_setup(sa_ctx *ctx)
 		slack = -o - e + 2;
 		floor_v = -o - 2 * e + 2;
 		q = o + e; /* (only its magnitude is used below: margins) */
-		extra = (int64_t)SA_SYS_CHUNK * ((int64_t)ctx->max_len + 1) * (-e) + 16 * (-e);
+		/* the drift of a tile grows with the length of its row streams: long sequences get shorter streams (a stream of
+		 * 8 sequences of 1000 residues is 8000 steps -- the per-tile costs are long amortised), so that the drift stays a
+		 * fraction of the u16 range and SW keeps the packed kernels whatever the longest sequence is */
+		int cap = SA_SYS_CHUNK;
+		while (cap > 4 && (int64_t)cap * ((int64_t)ctx->max_len + 1) * (-e) > 12000)
+			cap >>= 1;
+		ctx->pk_chunk_cap = cap;
+		extra = (int64_t)cap * ((int64_t)ctx->max_len + 1) * (-e) + 16 * (-e);
 	} else if (sc.method == SA_METHOD_NW) {
 		pconst = -2 * g;
 		pmax = smax + pconst;
@@ -976,6 +985,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 			cpk >>= 1;
 		if (ctx->env_chunk)
 			cpk = ctx->env_chunk;
+		cpk = std::min(cpk, ctx->pk_chunk_cap);
 		plan.chunk_pk = cpk;
 		/* Two tile sizes for a launch that gives a workgroup slot fewer than 16 tiles (one rank's share of a multi-GPU
 		 * run; a super-chunk): when the tiles run out the slots finish their last ones over a whole tile's duration, and
@@ -987,7 +997,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 			int32_t big = SA_SYS_CHUNK;
 			while (big > 16 && 2 * mine / ((int64_t)2 * SA_PK_WPB * 8 * big) < 5 * slots)
 				big >>= 1;
-			big = std::max(big, cpk);
+			big = std::min(std::max(big, cpk), ctx->pk_chunk_cap);
 			if (big >= 16) {
 				plan.chunk_pk = big;
 				plan.chunk_pk_small = std::max(4, big / 4);

@@ -25,13 +25,28 @@ def test_class_boundaries_and_padding(method, gaps, sa, oracle):
     for k in range(1, 25):
         lens += [8 * k - 1, 8 * k, 8 * k + 1] if k < 24 else [8 * k - 1, 8 * k]
     lens += [1, 2, 3, 5, 193, 200]  # below the first class; the first 16-lane class
-    for k in range(13, 41):           # 16-lane groups: W = 16 K = 208 .. 640 (classes whose range does not fit fall to
+    for k in range(13, 41):           # 16-lane groups: W = 16 K = 208 .. 640 here, 641 .. 1024 below (classes whose range does not fit fall to
         lens += [16 * k - 1, 16 * k, 16 * k + 1]  # the s32 kernels: with a 1-residue row in the store most of these)
     lens += [700, 1025]
     seqs = [seq_of(n, 1000 + i) for i, n in enumerate(lens)]
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
     assert np.array_equal(sa.hip_align(store, scoring, triangular=True), oracle.align(store, scoring, triangular=True))
+
+
+@pytest.mark.parametrize("method,gaps", METHODS)
+def test_wide_classes_up_to_1024_columns(method, gaps, sa, oracle):
+    """16-lane classes K = 41..64 (columns 641..1024: the row token is the profile offset in 256-byte units there), at
+    their boundaries 16K-1, 16K, 16K+1, in a store whose shortest sequence keeps one frame shift in flight -- so that
+    these columns really run on the packed kernels -- plus a column beyond 1024 (strip-mined s32 class) beside them"""
+    lens = [16, 17, 40, 100, 333]
+    for k in range(41, 65):
+        lens += [16 * k - 1, 16 * k] + ([16 * k + 1] if k < 64 else [])
+    lens += [1100]
+    seqs = [seq_of(n, 4000 + i) for i, n in enumerate(lens)]
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+    assert np.array_equal(sa.hip_align(store, scoring, triangular=True), oracle.align(store, scoring, triangular=True, threads=16))
 
 
 @pytest.mark.parametrize("method,gaps", METHODS)
