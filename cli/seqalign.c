@@ -26,7 +26,7 @@
 
 #include "sa_host.h"
 
-static bool quiet, verbose, force_yes;
+static bool quiet, verbose, force_yes, no_progress;
 
 static void info(const char *fmt, ...)
 {
@@ -109,7 +109,7 @@ static void usage(const char *argv0)
 	       "  -T, --threads N          Number of host threads (0 = auto)\n"
 	       "  -C, --no-cuda            Not available: this build has no CPU alignment path\n"
 	       "  -W, --no-write           Disable writing to output file\n"
-	       "  -P, --no-progress        Disable progress bars (accepted, no-op)\n"
+	       "  -P, --no-progress        Disable progress bars\n"
 	       "  -D, --no-detail          Disable detailed printing (accepted, no-op)\n"
 	       "  -F, --force-proceed      Force proceed without user prompts (for CI)\n"
 	       "  -Q, --quiet              Suppress all non-error printing\n"
@@ -230,7 +230,7 @@ static int parse_args(int argc, char **argv, struct options *o)
 				break;
 			case 'C': o->no_device = true; break;
 			case 'W': o->no_write = true; break;
-			case 'P':
+			case 'P': no_progress = true; break;
 			case 'D': break;
 			case 'F': force_yes = true; break;
 			case 'Q': quiet = true; break;
@@ -250,6 +250,13 @@ static int parse_args(int argc, char **argv, struct options *o)
 		} while (*++bundle);
 	}
 	return 0;
+}
+
+static void progress_line(double fraction, void *user)
+{
+	(void)user;
+	fprintf(stderr, "\rAligning sequences: %3d%%", (int)(fraction * 100.0));
+	fflush(stderr);
 }
 
 int main(int argc, char **argv)
@@ -392,13 +399,22 @@ int main(int argc, char **argv)
 		 * RAM by definition and stays pageable: the library stages those copies) */
 		if (!tmpf) {
 			const size_t bytes = sizeof(int32_t) * (out.triangular ? n * (n - 1) / 2 : n * n);
-			pinned = bytes && sa_hip_host_register(out.matrix, bytes) == 0;
+			/* (the library's own rule, sa_ctx_align_host: never lock more than half of what is available -- a
+			 * registration of 70 % of free RAM thrashes or meets the OOM killer instead of failing cleanly) */
+			const size_t avail = sa_host_available_memory();
+			pinned = bytes && (!avail || bytes <= avail / 2) && sa_hip_host_register(out.matrix, bytes) == 0;
 		}
 		t_out += now() - t0;
 	}
 
 	const long long pairs = (long long)n * ((long long)n - 1) / 2;
 	info("Performing %lld pairwise alignments", pairs);
+	/* progress (ppercent / pproportc in the reference's launch loop, src/interface/seqalign_cuda.c:181,286-289,293) */
+	const bool show_progress = !no_progress && !quiet;
+	if (show_progress) {
+		sa_hip_set_progress(progress_line, NULL);
+		progress_line(0.0, NULL);
+	}
 	verb("Devices: %d (%s)", sa_hip_device_count(), sa_hip_device_name(0) ? sa_hip_device_name(0) : "none");
 	t0 = now();
 	if (!sa_hip_align(store.in, out, &sc)) {
@@ -406,6 +422,11 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	t_align = now() - t0;
+	if (show_progress) {
+		progress_line(1.0, NULL);
+		fputc('\n', stderr);
+		sa_hip_set_progress(NULL, NULL);
+	}
 	/* the reference times the launch/copy loop only (bench_align_start..end inside cuda_align,
 	 * src/interface/seqalign_cuda.c:182,292): device set-up and uploads are not part of "Alignment" */
 	const double t_setup = t_align - sa_hip_last_align_seconds();

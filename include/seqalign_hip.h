@@ -227,6 +227,13 @@ int sa_method_gap_kind(int method);       /* enum sa_gap_kind               */
  * uploads, allocations and context set-up are outside it, the device->host copies inside). */
 double sa_hip_last_align_seconds(void);
 
+/* Progress of a running sa_hip_align / sa_ctx_align_host, the reference's ppercent / pproportc side channel
+ * (src/interface/seqalign_cuda.c:181,286-289,293): fn(fraction in [0,1], user) is called from the calling thread while it
+ * waits for the device -- per batch on the batched paths, every 50 ms from the launches' tile counters on the
+ * single-launch path.  NULL (the default) reports nothing and polls nothing. */
+typedef void (*sa_progress_fn)(double fraction, void *user);
+void sa_hip_set_progress(sa_progress_fn fn, void *user);
+
 /* Where the time of the last successful sa_hip_align() went, in milliseconds (its first slice): ms[k] for k of
  * enum sa_breakdown; returns the number of entries written.  Everything but SA_BREAKDOWN_PHASE is set-up the reference
  * keeps outside bench_align_start()/bench_align_end() as well (src/interface/seqalign_cuda.c:115-168). */

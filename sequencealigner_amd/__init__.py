@@ -35,9 +35,10 @@ from .binding import (  # noqa: F401
     matrix_names,
     method_names,
     pair_count,
+    set_progress,
 )
 
 __all__ = [
     "AlignError", "Context", "PinnedMatrix", "Scoring", "SequenceStore", "device_count", "device_name", "last_align_breakdown", "last_align_seconds", "hip_align", "hip_filter",
-    "hip_memory", "library_path", "load_library", "matrix_names", "method_names", "pair_count",
+    "hip_memory", "library_path", "load_library", "matrix_names", "method_names", "pair_count", "set_progress",
 ]

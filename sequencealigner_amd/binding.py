@@ -51,7 +51,7 @@ ABI_SYMBOLS = (
     "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name", "sa_last_error",
     "sa_abi_version",
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
-    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown", "sa_ctx_leave_room",
+    "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown", "sa_ctx_leave_room", "sa_hip_set_progress",
 )
 
 
@@ -147,6 +147,8 @@ def load_library() -> C.CDLL:
     lib.sa_hip_host_unregister.restype = C.c_int
     lib.sa_hip_last_align_breakdown.argtypes = [C.POINTER(C.c_double), C.c_int]
     lib.sa_hip_last_align_breakdown.restype = C.c_int
+    lib.sa_hip_set_progress.argtypes = [C.c_void_p, C.c_void_p]
+    lib.sa_hip_set_progress.restype = None
     lib.sa_ctx_leave_room.argtypes = [C.c_void_p, C.c_int]
     lib.sa_ctx_leave_room.restype = None
     lib.sa_ctx_share_elems.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int]
@@ -178,6 +180,23 @@ def last_align_breakdown() -> dict:
     buf = (C.c_double * len(names))()
     n = load_library().sa_hip_last_align_breakdown(buf, len(names))
     return {names[k]: float(buf[k]) for k in range(n)}
+
+
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_double, C.c_void_p)
+_progress_keepalive = None
+
+
+def set_progress(fn) -> None:
+    """fn(fraction) while hip_align / Context.align_host waits for the device (the reference's progress side channel,
+    seqalign_cuda.c:286-289); None switches it off"""
+    global _progress_keepalive
+    lib = load_library()
+    if fn is None:
+        lib.sa_hip_set_progress(None, None)
+        _progress_keepalive = None
+        return
+    _progress_keepalive = PROGRESS_FN(lambda fraction, _user: fn(float(fraction)))
+    lib.sa_hip_set_progress(C.cast(_progress_keepalive, C.c_void_p), None)
 
 
 def device_name(device: int = 0) -> str:

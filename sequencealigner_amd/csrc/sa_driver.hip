@@ -170,6 +170,12 @@ struct sa_ctx {
 	bool env_serial_classes = false, env_stamps = false, env_no_pin = false, env_no_shells = false, env_no_direct = false;
 	int env_chunk = 0, env_stagger = 0, env_pk_wgs = 0;
 	bool leave_room = false; /* sa_ctx_leave_room */
+	/* progress reporting (sa_hip_set_progress): the tile counters of the launches of the last sa_ctx_align_range call */
+	struct ProgItem {
+		const unsigned *counter;
+		int64_t tiles;
+	};
+	std::vector<ProgItem> prog_items;
 	/* where the set-up time of this context went, milliseconds (sa_hip_last_align_breakdown) */
 	struct SetupMs {
 		double encode = 0, device = 0, upload = 0, code_objects = 0, pin = 0, plan = 0, arrange = 0;
@@ -191,6 +197,20 @@ namespace {
 void deliver_release(sa_ctx *ctx);
 }
 
+static std::atomic<sa_progress_fn> g_progress_fn{ nullptr };
+static std::atomic<void *> g_progress_user{ nullptr };
+
+extern "C" void sa_hip_set_progress(sa_progress_fn fn, void *user)
+{
+	g_progress_user.store(user);
+	g_progress_fn.store(fn);
+}
+
+static void report_progress(double fraction)
+{
+	if (sa_progress_fn fn = g_progress_fn.load())
+		fn(fraction < 0 ? 0 : fraction > 1 ? 1 : fraction, g_progress_user.load());
+}
 static double ms_since(std::chrono::steady_clock::time_point t0)
 {
 	return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1660,6 +1680,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 	}
 	hipStream_t caller = s;
 	int launch_no = 0;
+	ctx->prog_items.clear();
 	for (const Item &it : items) {
 		const int side_k = launch_no++ % sa_ctx::NSIDE;
 		if (fan_out) {
@@ -1758,6 +1779,7 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			SA_HIP_CHECK(hipMemset(d_stamps, 0, sizeof(unsigned long long) * stamp_words), return 1);
 			a.stamps = d_stamps;
 		}
+		ctx->prog_items.push_back({ a.counter, ntiles_here });
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		if (!timed_begin(e0, e1))
 			return 1;
@@ -2119,6 +2141,10 @@ bool deliver_full_shells(sa_ctx *ctx, int64_t j0, int64_t j1, int32_t *matrix, d
 						      dim * sizeof(int32_t), (size_t)(jb - ja) * sizeof(int32_t), (size_t)ja,
 						      hipMemcpyDeviceToHost, d.copy), return false);
 		}
+		if (g_progress_fn.load() && b + 2 < cuts.size()) { /* (batches issued so far; the host runs ahead of the device by one) */
+			SA_HIP_CHECK(hipEventSynchronize(d.done[0]), return false);
+			report_progress((double)(tri_of(jb) - start) / (double)std::max<int64_t>(1, tri_of(j1) - start));
+		}
 	}
 	SA_HIP_CHECK(hipStreamSynchronize(d.compute), return false);
 	SA_HIP_CHECK(hipStreamSynchronize(d.copy), return false);
@@ -2151,6 +2177,7 @@ bool deliver_batches(sa_ctx *ctx, int64_t lo, int64_t total, const sa_output &ou
 			host_scatter_full(out.matrix, dim, d.h_stage[pd.buf], pd.start, pd.count);
 		pend[0] = pend[1];
 		npend--;
+		report_progress((double)(pd.start + pd.count - lo) / (double)std::max<int64_t>(1, total));
 		return true;
 	};
 	while (issued < total) {
@@ -2303,6 +2330,38 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 		ctx->out_is_host = true;
 		ok = sa_ctx_align_range(ctx, start, total, direct, d.compute) == 0;
 		ctx->out_is_host = false;
+		if (ok && g_progress_fn.load() && !ctx->prog_items.empty()) {
+			/* Progress (the reference's pproportc in its batch loop, src/interface/seqalign_cuda.c:286-289): one launch does
+			 * the whole range here, so the host reads the launches' tile counters every 50 ms while it waits.  A counter
+			 * goes back to zero when its launch ends: fractions only ever grow. */
+			unsigned *h_cnt = nullptr;
+			const size_t nit = ctx->prog_items.size();
+			int64_t all = 0;
+			for (const auto &it : ctx->prog_items)
+				all += it.tiles;
+			double shown = 0.0;
+			if (hipHostMalloc(reinterpret_cast<void **>(&h_cnt), sizeof(unsigned) * nit) == hipSuccess) {
+				std::vector<int64_t> seen(nit, 0);
+				while (hipStreamQuery(d.compute) == hipErrorNotReady) {
+					std::this_thread::sleep_for(std::chrono::milliseconds(50));
+					bool got = true;
+					for (size_t k = 0; k < nit && got; k++)
+						got = hipMemcpyAsync(&h_cnt[k], ctx->prog_items[k].counter, sizeof(unsigned), hipMemcpyDeviceToHost, d.copy) == hipSuccess;
+					if (!got || hipStreamSynchronize(d.copy) != hipSuccess)
+						break;
+					int64_t done = 0;
+					for (size_t k = 0; k < nit; k++) {
+						seen[k] = std::max(seen[k], std::min<int64_t>(h_cnt[k], ctx->prog_items[k].tiles));
+						done += seen[k];
+					}
+					const double f = all ? (double)done / (double)all : 0.0;
+					if (f > shown)
+						report_progress(shown = f);
+				}
+				(void)hipGetLastError();
+				(void)hipHostFree(h_cnt);
+			}
+		}
 		if (ok) {
 			SA_HIP_CHECK(hipStreamSynchronize(d.compute), ok = false);
 		}

@@ -69,3 +69,17 @@ def test_cli_dsv_filter_and_flags(tmp_path):
                 ["-a", "nw", "-m", "nope", "-p", 1], ["-a", "xx", "-m", "blosum62", "-p", 1]):
         res = run("-i", csv, "-W", *bad, check=False)
         assert res.returncode == 1 and "usage information" in res.stderr
+
+
+def test_cli_progress_line(tmp_path):
+    """without -P the tool reports progress on stderr like the reference (ppercent / pproportc, seqalign_cuda.c:181,286-293);
+    -P and -Q switch it off"""
+    from tests.synth import make_dna_set
+    seqs = make_dna_set(3000, 120, 180, 4)
+    fasta = tmp_path / "in.fasta"
+    write_fasta(fasta, seqs)
+    res = run("-i", fasta, "-W", "-a", "sw", "-m", "nuc44", "-s", 10, "-e", 1, "-F")
+    assert "Aligning sequences:   0%" in res.stderr and "Aligning sequences: 100%" in res.stderr
+    for flag in ("-P", "-Q"):
+        res = run("-i", fasta, "-W", "-a", "sw", "-m", "nuc44", "-s", 10, "-e", 1, "-F", flag)
+        assert "Aligning sequences" not in res.stderr

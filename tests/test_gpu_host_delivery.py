@@ -94,3 +94,33 @@ def test_two_physical_devices_when_visible(sa, oracle):
         assert np.array_equal(sa.hip_align(store, scoring, triangular=True), want)
         assert np.array_equal(sa.hip_align(store, scoring, triangular=False), tri_to_full(want, store.num))
     assert sa.hip_memory(1 << 20)
+
+
+def test_progress_side_channel(sa, oracle):
+    """sa_hip_set_progress: fractions in [0, 1], never decreasing, while the result stays the reference's (the single-launch
+    direct-store path polls the launches' tile counters; the batched paths report per batch)"""
+    from tests.synth import make_dna_set
+    seqs = make_dna_set(9000, 120, 180, 4)  # ~100 ms of SW: a few 50 ms polls
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names("sw", "nuc44", gap_open=10, gap_extend=1)
+    seen = []
+    sa.set_progress(seen.append)
+    try:
+        dest = sa.PinnedMatrix(store.pairs)
+        try:
+            with sa.Context(store, scoring, 0) as ctx:
+                ctx.align_host(dest.array, triangular=True)
+            direct = list(seen)
+            idx = np.sort(np.random.default_rng(3).integers(0, store.pairs, 20000))
+            assert np.array_equal(dest.array[idx], oracle.align_pairs(store, scoring, idx, threads=16))
+        finally:
+            dest.close()
+        del seen[:]
+        small = store.prefix(1500)
+        full = sa.hip_align(small, scoring, triangular=False)  # full layout: shells, per batch
+        assert np.array_equal(full, full.T)
+    finally:
+        sa.set_progress(None)
+    assert direct, "no progress was reported during a ~100 ms launch"
+    for fr in (direct, seen):
+        assert all(0.0 <= f <= 1.0 for f in fr) and all(a <= b for a, b in zip(fr, fr[1:]))
