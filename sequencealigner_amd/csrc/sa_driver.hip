@@ -1158,7 +1158,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 			int32_t cls_idx, t, owner;
 			int32_t j[2], ia[2], ib[2], i_begin, i_count;
 			bool dup, own; /* own: an arranged tile that is its whole block (its rows are a permutation of its positions) */
-			const int32_t *rowmap;
+			const int32_t *rowmap, *posmap;
 			int64_t doff;
 		};
 		std::vector<Geo> geo;
@@ -1201,6 +1201,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 					g.i_count = std::min(rows, rb - g.i_begin);
 					const int l = sa_pk_pick_level(lvrows, ra, rb, g.i_begin, rows);
 					g.rowmap = l >= 0 ? lv[l].rowmap : nullptr;
+					g.posmap = l >= 0 ? lv[l].posmap : nullptr;
 					g.own = l >= 0 && lv[l].rows == g.i_count;
 				}
 			} else {
@@ -1217,7 +1218,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 						g.ia[0] = g.ia[1] = ia, g.ib[0] = g.ib[1] = ib;
 						g.i_begin = ia + (t - T[(size_t)k]) * rows;
 						g.i_count = std::min(rows, ib - g.i_begin);
-						g.rowmap = nullptr;
+						g.rowmap = g.posmap = nullptr;
 						g.own = false;
 					}
 				}
@@ -1291,7 +1292,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 				SaPlaceSeg sg{};
 				sg.src = (int64_t)g.owner * plan.share_elems + g.doff + (int64_t)h * SA_SHARE_PAD(g.i_count);
 				sg.dst = (int64_t)g.j[h] * (g.j[h] - 1) / 2 - start;
-				sg.rowmap = g.rowmap;
+				sg.map = g.own ? g.posmap : g.rowmap;
 				sg.count = g.i_count;
 				sg.pos0 = g.i_begin;
 				sg.ia = g.ia[h];
@@ -1305,7 +1306,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 					SaPlaceSeg sg{};
 					sg.src = (int64_t)r * plan.share_elems + gs.doff + o;
 					sg.dst = gs.start + o - start;
-					sg.rowmap = nullptr;
+					sg.map = nullptr;
 					sg.count = (int32_t)std::min<int64_t>(8192, gs.count - o);
 					sg.pos0 = 0;
 					sg.ia = 0;

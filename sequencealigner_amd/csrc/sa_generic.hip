@@ -301,43 +301,40 @@ __global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__
 {
 	/* One WAVE per run and pass (a run is at most a tile's rows; a workgroup per run was 240 000 workgroups of one
 	 * iteration each for cfg 2 at 8 ranks -- 0.45 ms of dispatch).  A tile that is its own arranged block holds a
-	 * permutation of the rows [pos0, pos0 + count): it is un-permuted in LDS and leaves as contiguous 16-byte stores --
-	 * scattered 4-byte stores made the L2 write partial lines (1.2 TB/s for the whole pass). */
-	constexpr int OWN_MAX = 1024;
-	__shared__ int32_t s_rows[4][OWN_MAX];
-	const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+	 * permutation of the rows [pos0, pos0 + count): it is placed OUTPUT-driven -- a lane takes four consecutive rows,
+	 * looks their positions up (posmap: one 16-byte load), gathers the four scores from the run (a 1-2 KB window) and
+	 * stores 16 contiguous bytes.  Position-driven scattering made the L2 write partial lines (1.2 TB/s for the pass). */
+	const int lane = threadIdx.x & 63;
+	const int32_t wave = (int32_t)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int32_t)(gridDim.x * 4);
 	typedef int32_t i32x4 __attribute__((ext_vector_type(4), aligned(4)));
-	for (int32_t base = (int32_t)blockIdx.x * 4; base < nsegs; base += (int32_t)gridDim.x * 4) { /* (uniform trip count) */
-		const int32_t k = base + w;
-		SaPlaceSeg sg{};
-		if (k < nsegs)
-			sg = segs[k];
+	for (int32_t k = wave; k < nsegs; k += nwaves) {
+		const SaPlaceSeg sg = segs[k];
 		const T *src = shares + sg.src;
 		int32_t *dst = packed + sg.dst;
-		const bool own = sg.rowmap && (sg.flags & 1) && sg.count <= OWN_MAX;
-		if (own)
-			for (int32_t p = lane; p < sg.count; p += 64)
-				s_rows[w][sg.rowmap[sg.pos0 + p] - sg.pos0] = (int32_t)src[p];
-		__syncthreads();
-		if (own) {
+		if (sg.flags & 1) { /* map = posmap (row -> position), rows [pos0, pos0 + count) */
+#pragma unroll 2
 			for (int32_t q = 4 * lane; q < sg.count; q += 256) {
 				const int32_t r = sg.pos0 + q;
-				if (r >= sg.ia && r + 4 <= sg.ib && q + 4 <= sg.count) {
-					*reinterpret_cast<i32x4 *>(dst + r) = *reinterpret_cast<const i32x4 *>(&s_rows[w][q]);
-				} else {
-					for (int e = 0; e < 4 && q + e < sg.count; e++)
-						if (r + e >= sg.ia && r + e < sg.ib)
-							dst[r + e] = s_rows[w][q + e];
+				if (q + 4 <= sg.count) {
+					const i32x4 pp = *reinterpret_cast<const i32x4 *>(sg.map + r);
+					const i32x4 v = { (int32_t)src[pp.x - sg.pos0], (int32_t)src[pp.y - sg.pos0], (int32_t)src[pp.z - sg.pos0],
+							  (int32_t)src[pp.w - sg.pos0] };
+					if (r >= sg.ia && r + 4 <= sg.ib) {
+						*reinterpret_cast<i32x4 *>(dst + r) = v;
+						continue;
+					}
 				}
+				for (int e = 0; e < 4 && q + e < sg.count; e++)
+					if (r + e >= sg.ia && r + e < sg.ib)
+						dst[r + e] = (int32_t)src[sg.map[r + e] - sg.pos0];
 			}
-		} else {
+		} else { /* map = rowmap (position -> row) or null (store order) */
 			for (int32_t p = lane; p < sg.count; p += 64) {
-				const int32_t r = sg.rowmap ? sg.rowmap[sg.pos0 + p] : sg.pos0 + p;
+				const int32_t r = sg.map ? sg.map[sg.pos0 + p] : sg.pos0 + p;
 				if (r >= sg.ia && r < sg.ib)
 					dst[r] = (int32_t)src[p];
 			}
 		}
-		__syncthreads();
 	}
 }
 
@@ -345,7 +342,7 @@ hipError_t sa_launch_place(const SaPlaceSeg *segs, int32_t nsegs, const void *sh
 {
 	if (nsegs <= 0)
 		return hipSuccess;
-	const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)nsegs + 3) / 4, 256 * 10); /* 16 KB of LDS each: 10 per CU */
+	const unsigned blocks = (unsigned)std::min<int64_t>(((int64_t)nsegs + 3) / 4, 256 * 8);
 	if (elem16)
 		hipLaunchKernelGGL(sa_k_place<int16_t>, dim3(blocks), dim3(256), 0, s, segs, nsegs, static_cast<const int16_t *>(shares), packed);
 	else

@@ -210,11 +210,13 @@ __host__ __device__ inline int sa_pk_pick_level(const int32_t *lvrows, int32_t r
 }
 
 /* one run of a dense share and where it goes in the packed matrix (sa_k_place): element p of the run is the score of
- * row r = rowmap ? rowmap[pos0 + p] : pos0 + p, stored at packed[dst + r] if ia <= r < ib */
+ * row r = map ? map[pos0 + p] : pos0 + p, stored at packed[dst + r] if ia <= r < ib.  A run whose rows are exactly a
+ * permutation of [pos0, pos0 + count) (flags bit 0: an arranged tile that is its whole block) carries the INVERSE map
+ * instead (posmap: row -> position) and is placed row by row. */
 struct SaPlaceSeg {
 	int64_t src;           /* element offset in the gathered shares (rank-major)                 */
 	int64_t dst;           /* tri(j) - start of the placed range; generic runs: run start - start */
-	const int32_t *rowmap; /* arranged tiles: position -> row                                     */
+	const int32_t *map;    /* arranged tiles: position -> row; flags bit 0: row -> position       */
 	int32_t count, pos0, ia, ib;
 	int32_t flags;         /* bit 0: the run's rows are a permutation of [pos0, pos0 + count)     */
 	int32_t pad_;

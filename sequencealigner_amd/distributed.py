@@ -251,7 +251,9 @@ class TiledGatherStep:
             # ONE compute stream: the super-chunks' kernels run one after the other (on streams of their own they would all
             # start together and finish together -- nothing for the gather of the first one to hide behind)
             self.compute = torch.cuda.Stream()
-            self.comm, self.deliver = torch.cuda.Stream(), torch.cuda.Stream()
+            # the placement follows the all-gather on the SAME stream: one cross-stream hop (~15 us each) fewer per super-chunk
+            self.comm = torch.cuda.Stream()
+            self.deliver = self.comm
             self._event = torch.cuda.Event
         else:
             self.main = self.compute = self.comm = self.deliver = _Inline()
@@ -281,9 +283,9 @@ class TiledGatherStep:
                 with (torch.cuda.stream(self.comm) if cuda else _null()):
                     # (the process group moves bytes; int16 is not among its dtypes, uint8 is)
                     dist.all_gather_into_tensor(self.shares[c].view(torch.uint8), self.my_share(c).view(torch.uint8))
-                gathered = self._event()
-                gathered.record(self.comm)
-            self.deliver.wait_event(gathered)
+                gathered = None  # (same stream as the placement below)
+            if gathered is not None:
+                self.deliver.wait_event(gathered)
             be.place(lo, cnt, self.world, self.shares[c], self.packed[lo:lo + cnt], self.deliver)
         fin = self._event()
         fin.record(self.deliver)
