@@ -252,6 +252,17 @@ static int parse_args(int argc, char **argv, struct options *o)
 	return 0;
 }
 
+/* SA_CLI_TIMES=1 (diagnostics): wall-clock stamps of the tool's stages on stderr */
+static double t_process0;
+static void stamp(const char *what)
+{
+	static int on = -1;
+	if (on < 0)
+		on = getenv("SA_CLI_TIMES") != NULL;
+	if (on)
+		fprintf(stderr, "[cli %8.1f ms] %s\n", (now() - t_process0) * 1e3, what);
+}
+
 static void progress_line(double fraction, void *user)
 {
 	(void)user;
@@ -261,6 +272,7 @@ static void progress_line(double fraction, void *user)
 
 int main(int argc, char **argv)
 {
+	t_process0 = now();
 	struct options o;
 	const int prc = parse_args(argc, argv, &o);
 	if (prc == 2)
@@ -350,6 +362,7 @@ int main(int argc, char **argv)
 		info("Filter threshold: %.1f%%", (double)o.filter * 100.0);
 
 	double t_in = 0, t_filter = 0, t_align = 0, t_out = 0, t0;
+	stamp("options parsed");
 	struct sa_host_store store;
 	t0 = now();
 	if (sa_host_load(o.input, sc.lut, sc.gap_pen, o.dsv_column, o.dsv_has_header, &store)) {
@@ -357,6 +370,7 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	t_in = now() - t0;
+	stamp("input loaded");
 	t0 = now();
 	const int32_t before = store.in.num;
 	if (o.filter > 0.0f) { /* similarity relation on the device, greedy keep/drop in sequence order (filter.c:14-89) */
@@ -386,6 +400,7 @@ int main(int argc, char **argv)
 		const size_t full_bytes = sizeof(int32_t) * n * n;
 		const bool tmpf = sa_host_matrix_needs_file(n);
 		out.triangular = tmpf || !sa_hip_memory(full_bytes);
+		stamp("device memory probed (runtime up)");
 		info("Similarity Matrix dimensions: %zu x %zu%s", n, n, out.triangular ? " (stored triangular)" : "");
 		if (tmpf)
 			info("Similarity Matrix size exceeds memory limits, creating temporary file storage");
@@ -395,6 +410,7 @@ int main(int argc, char **argv)
 			err("%s", sa_host_error());
 			return 1;
 		}
+		stamp("matrix allocated");
 		/* page-lock it for the device->host copies while it is being set up (a file-backed matrix is larger than
 		 * RAM by definition and stays pageable: the library stages those copies) */
 		if (!tmpf) {
@@ -405,6 +421,7 @@ int main(int argc, char **argv)
 			pinned = bytes && (!avail || bytes <= avail / 2) && sa_hip_host_register(out.matrix, bytes) == 0;
 		}
 		t_out += now() - t0;
+		stamp("matrix page-locked");
 	}
 
 	const long long pairs = (long long)n * ((long long)n - 1) / 2;
@@ -422,6 +439,7 @@ int main(int argc, char **argv)
 		return 1;
 	}
 	t_align = now() - t0;
+	stamp("sa_hip_align returned");
 	if (show_progress) {
 		progress_line(1.0, NULL);
 		fputc('\n', stderr);
@@ -439,6 +457,7 @@ int main(int argc, char **argv)
 			return 1;
 		}
 		t_out += now() - t0;
+		stamp("HDF5 written");
 	}
 	if (o.benchmark) { /* -B: src/util/benchmark.c:50-64 */
 		const double total = t_in + t_filter + t_align + t_out;
@@ -452,5 +471,9 @@ int main(int argc, char **argv)
 		sa_hip_host_unregister(out.matrix);
 	sa_host_matrix_free(out.matrix, n, out.triangular);
 	sa_host_store_free(&store);
-	return 0;
+	stamp("released");
+	/* everything is written and closed: leave without the runtime's teardown (device reset, queue and signal
+	 * destruction: ~0.15 s that nothing waits for) */
+	fflush(NULL);
+	_exit(0);
 }

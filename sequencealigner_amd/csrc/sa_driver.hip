@@ -25,11 +25,6 @@
 #include <unistd.h>
 #include <chrono>
 
-/* The class launches of a range run concurrently, one stream each; the HIP runtime multiplexes streams onto
- * GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's), and kernels that share a queue run one
- * after the other: with the default, cfg 2's six classes ran as two rounds of three, each round with its own tail
- * (profiles/r03a_*).  The variable is read when the runtime initialises, so it is set when this library is loaded --
- * unless the user has set it. */
 /* SA_HIP_ABORT_TRACE=<file> (diagnostics): a C backtrace of whoever raises SIGABRT in this process, appended to the file */
 static char g_abort_trace_path[512];
 static void sa_abort_trace(int)
@@ -47,7 +42,6 @@ static void sa_abort_trace(int)
 
 __attribute__((constructor)) static void sa_runtime_knobs(void)
 {
-	setenv("GPU_MAX_HW_QUEUES", "12", 0);
 	if (const char *p = getenv("SA_HIP_ABORT_TRACE")) {
 		snprintf(g_abort_trace_path, sizeof(g_abort_trace_path), "%s", p);
 		signal(SIGABRT, sa_abort_trace);
@@ -625,16 +619,8 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		if (verbose)
 			fprintf(stderr, "[seqalign_hip] sa_ctx_create: scratch at %.1f ms\n", since());
 		ctx->persistent_wgs = prop.multiProcessorCount * 32;
-		bool streams_ok = true;
-		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming), streams_ok = false);
-		for (int k = 0; k < sa_ctx::NSIDE && streams_ok; k++) {
-			SA_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking), streams_ok = false);
-			if (streams_ok) {
-				SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming), streams_ok = false);
-			}
-		}
-		if (!streams_ok)
-			break;
+		/* (the side streams of a range with several launches are created when the first such range comes: a store whose
+		 * columns fall into one bundle -- the usual case -- never needs them, and eight streams cost ~70 ms of set-up) */
 		/* code objects are loaded lazily at the first launch: do it here, with the other set-up */
 		/* code objects of the kernel families this store's columns fall into (plan_build's class choice) */
 		int families = 0;
@@ -1677,6 +1663,14 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 	}
 	/* (the counters are zero: set so once at context creation, and every launch's last workgroup puts its own back) */
 	if (fan_out) {
+		if (!ctx->fork_ev) {
+			SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming), return 1);
+		}
+		for (int k = 0; k < sa_ctx::NSIDE && k < (int)items.size(); k++)
+			if (!ctx->side[k]) {
+				SA_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side[k], hipStreamNonBlocking), return 1);
+				SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->join_ev[k], hipEventDisableTiming), return 1);
+			}
 		SA_HIP_CHECK(hipEventRecord(ctx->fork_ev, s), return 1);
 	}
 	hipStream_t caller = s;
