@@ -162,7 +162,7 @@ struct sa_ctx {
 	std::vector<Timed> events;
 	/* development switches, read once when the context is created */
 	bool env_serial_classes = false, env_stamps = false, env_no_pin = false, env_no_shells = false, env_no_direct = false;
-	int env_chunk = 0, env_stagger = 0, env_pk_wgs = 0;
+	int env_chunk = 0, env_stagger = 0, env_pk_wgs = 0, env_rotate_prio = -1; /* (-1: by method) */
 	bool leave_room = false; /* sa_ctx_leave_room */
 	/* progress reporting (sa_hip_set_progress): the tile counters of the launches of the last sa_ctx_align_range call */
 	struct ProgItem {
@@ -573,6 +573,8 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 	ctx->env_no_shells = getenv("SA_HIP_NO_SHELLS") != nullptr;
 	ctx->env_no_direct = getenv("SA_HIP_NO_DIRECT") != nullptr;
 	ctx->env_no_sort = getenv("SA_HIP_NO_SORT") != nullptr;
+	if (const char *e = getenv("SA_HIP_ROTATE_PRIO")) /* development switch: 0 = every wave at priority 0 (oldest first) */
+		ctx->env_rotate_prio = atoi(e) != 0;
 	if (const char *e = getenv("SA_HIP_PK_WGS")) /* development switch: persistent workgroups of a packed launch */
 		ctx->env_pk_wgs = std::max(0, atoi(e));
 	if (const char *e = getenv("SA_HIP_STAGGER"))
@@ -1006,12 +1008,14 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 			big = std::min(std::max(big, cpk), ctx->pk_chunk_cap);
 			if (big >= 16) {
 				plan.chunk_pk = big;
-				plan.chunk_pk_small = std::max(4, big / 4);
+				const int sdiv = getenv("SA_HIP_SMALL_DIV") ? std::max(2, atoi(getenv("SA_HIP_SMALL_DIV"))) : 4;   /* (experiments) */
+				const int sfrac = getenv("SA_HIP_SMALL_FRAC") ? std::max(2, atoi(getenv("SA_HIP_SMALL_FRAC"))) : 5;
+				plan.chunk_pk_small = std::max(4, big / sdiv);
 				const int64_t jlo = column_of(start), jhi = column_of(end - 1) + 1;
 				int64_t lo = jlo, hi = jhi; /* smallest column with >= a fifth of the range's pairs below it */
 				while (lo < hi) {
 					const int64_t mid = (lo + hi) / 2;
-					if (mid * (mid - 1) / 2 - start >= count / 5)
+					if (mid * (mid - 1) / 2 - start >= count / sfrac)
 						hi = mid;
 					else
 						lo = mid + 1;
@@ -1710,6 +1714,9 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 			a.pk_f16 = pb->f16;
 			a.chunk = ctx->plan->chunk_pk; /* (the kernel takes chunk and arranged copies of every tile from its class block) */
 			a.stagger = ctx->env_stagger;
+			/* (measured: Gotoh's share of cfg 3 at 8 ranks 5.08 -> 5.01 ms, at 4 ranks 97.0 -> 98.0 % of ideal; NW needs all four
+			 * waves to fill a SIMD, nobody starves, and the rotation costs it 1 %) */
+			a.rotate_prio = ctx->env_rotate_prio >= 0 ? ctx->env_rotate_prio : ctx->sc.method != SA_METHOD_NW;
 			a.pkc = pb->d_args;
 			a.ulist = pb->d_ulist + pb->ufirst[(size_t)rk];
 			a.npkc = (int32_t)pb->cls.size();
@@ -1813,6 +1820,12 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 					for (int b = (int)a0; b < BINS && b <= (int)a1; b++)
 						act[b] += std::min(a1, (double)b + 1) - std::max(a0, (double)b);
 				}
+				if (const char *dump = getenv("SA_HIP_STAMPS_DUMP")) { /* raw words for offline analysis (7 per tile, see the kernel) */
+					if (FILE *f = fopen(dump, "wb")) {
+						fwrite(h.data(), sizeof(h[0]), h.size(), f);
+						fclose(f);
+					}
+				}
 				double clocks = 0, pro = 0, loop = 0, epi = 0, steps = 0;
 				for (size_t k = 0; k < nstamp; k++) {
 					const unsigned long long c0 = h[3 * k + 2], c1 = h[3 * nstamp + 3 * k], c2 = h[3 * nstamp + 3 * k + 1], c3 = h[6 * nstamp + k];
@@ -1828,6 +1841,21 @@ static int align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *
 					name, nstamp, span / 100.0, busy / (double)nstamp / 100.0, clocks / (double)nstamp, clocks / busy * 100.0, busy / span);
 				for (int b = 0; b < BINS; b++)
 					fprintf(stderr, " %.0f", act[b]);
+				/* ... and the last tenth of the launch in hundredths, with the mean rows of the tiles that END there */
+				double fine[10] = {}, rows_end[10] = {}, n_end[10] = {};
+				for (size_t k = 0; k < nstamp; k++) {
+					const double a0 = ((double)(h[3 * k] - t_lo) / span - 0.9) * 100.0, a1 = ((double)(h[3 * k + 1] - t_lo) / span - 0.9) * 100.0;
+					for (int b = std::max(0, (int)a0); b < 10 && b <= (int)a1; b++)
+						fine[b] += std::min(a1, (double)b + 1) - std::max(a0, (double)b);
+					if (a1 >= 0) {
+						const int b = std::min(9, (int)a1);
+						rows_end[b] += (double)h[3 * nstamp + 3 * k + 2];
+						n_end[b] += 1;
+					}
+				}
+				fprintf(stderr, "; per 1%% of the last tenth (mean steps of the tiles ending there):");
+				for (int b = 0; b < 10; b++)
+					fprintf(stderr, " %.0f(%.0f)", fine[b], n_end[b] ? rows_end[b] / n_end[b] : 0.0);
 				fprintf(stderr, "\n");
 			} else {
 				double cyc = 0, rt = 0, steps = 0;
@@ -2215,8 +2243,12 @@ extern "C" int sa_hip_host_register(void *p, size_t bytes)
 		sa_set_error("sa_hip_host_register: null range");
 		return 1;
 	}
-	if (!device_ready(0))
+	/* (the calling thread's current device is left alone: in a one-process-per-GPU host it is the rank's own device, and a
+	 * portable registration serves every device anyway) */
+	if (sa_hip_device_count() <= 0) {
+		sa_set_error("No HIP devices available; libseqalign_hip has no CPU fallback");
 		return 1;
+	}
 	SA_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterPortable), return 1);
 	return 0;
 }

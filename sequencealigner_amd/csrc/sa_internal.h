@@ -180,6 +180,7 @@ struct SaSysArgs {
 	int32_t npkc;
 	unsigned *counter;       /* [0] next unclaimed tile of this launch, [1] workgroups that have left; both zero before
 	                          * the launch and put back to zero by its last workgroup                           */
+	int32_t rotate_prio;        /* packed bundle: rotate the waves' issue priority tile by tile (sa_systolic_pk.inc)     */
 	int32_t stagger;            /* packed bundle: sleep periods (8128 clocks) per wave slot before the first tile      */
 	int32_t stamp_u;            /* diagnostics: launch-tile index of the tile being run (packed bundle)                */
 	unsigned long long *stamps; /* diagnostics only (SA_HIP_STAMPS=1): per wave-tile {cycles, 100MHz ticks,
