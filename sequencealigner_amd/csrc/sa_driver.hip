@@ -628,7 +628,9 @@ extern "C" sa_ctx *sa_ctx_create(int device, struct sa_input in, const struct sa
 		int families = 0;
 		for (int32_t k = 0; k < in.num; k++) {
 			const int n = in.meta[k].len, k8 = (n + 7) / 8, k16 = (n + 15) / 16;
-			families |= k8 <= ctx->pk_kmax ? SA_WARM_PK8 : (k16 >= SA_PK_K16_MIN && k16 <= ctx->pk16_kmax) ? SA_WARM_PK16 : SA_WARM_S32;
+			families |= k8 <= ctx->pk_kmax ? SA_WARM_PK8
+				    : (k16 >= SA_PK_K16_MIN && k16 <= ctx->pk16_kmax) ? (sa_pk_bundle_klo(16, k16) >= 45 ? SA_WARM_PK16HI : SA_WARM_PK16)
+										       : SA_WARM_S32;
 		}
 		if (verbose)
 			fprintf(stderr, "[seqalign_hip] sa_ctx_create: buffers, streams and events at %.1f ms\n", since());

@@ -231,7 +231,7 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workg
 hipError_t sa_launch_systolic_pk(int method, int g, int klo, int f16, const SaSysArgs &a, int workgroups, unsigned lds_bytes,
 				 hipStream_t s);
 /* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */
-enum : int { SA_WARM_S32 = 1, SA_WARM_PK8 = 2, SA_WARM_PK16 = 4 }; /* kernel families (one code object each per method) */
+enum : int { SA_WARM_S32 = 1, SA_WARM_PK8 = 2, SA_WARM_PK16 = 4, SA_WARM_PK16HI = 8 }; /* kernel families (one code object each per method) */
 hipError_t sa_warm_kernels(int method, int families);
 
 /* ---- launchers implemented in the .hip files ---------------------------- */

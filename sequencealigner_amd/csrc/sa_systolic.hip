@@ -22,6 +22,8 @@ hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int tiles
 #define SA_PK_DECL(M)                                                                                  \
 	hipError_t sa_launch_systolic_pk_##M(int g, int klo, int f16, const SaSysArgs &a, int wgs, unsigned lds, hipStream_t s);   \
 	hipError_t sa_launch_systolic_pk16_##M(int g, int klo, int f16, const SaSysArgs &a, int wgs, unsigned lds, hipStream_t s); \
+	hipError_t sa_launch_systolic_pk16hi_##M(int g, int klo, int f16, const SaSysArgs &a, int wgs, unsigned lds, hipStream_t s); \
+	hipError_t sa_warm_systolic_pk16hi_##M(void);                                                       \
 	hipError_t sa_warm_systolic_pk_##M(void);                                                           \
 	hipError_t sa_warm_systolic_pk16_##M(void);                                                         \
 	hipError_t sa_warm_systolic_##M(void);
@@ -35,11 +37,11 @@ hipError_t sa_launch_systolic_pk(int method, int g, int klo, int f16, const SaSy
 {
 	switch (method) {
 	case SA_METHOD_NW:
-		return g == 8 ? sa_launch_systolic_pk_nw(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_nw(g, klo, f16, a, wgs, lds, s);
+		return g == 8 ? sa_launch_systolic_pk_nw(g, klo, f16, a, wgs, lds, s) : (klo >= 45 ? sa_launch_systolic_pk16hi_nw(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_nw(g, klo, f16, a, wgs, lds, s));
 	case SA_METHOD_GA:
-		return g == 8 ? sa_launch_systolic_pk_ga(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_ga(g, klo, f16, a, wgs, lds, s);
+		return g == 8 ? sa_launch_systolic_pk_ga(g, klo, f16, a, wgs, lds, s) : (klo >= 45 ? sa_launch_systolic_pk16hi_ga(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_ga(g, klo, f16, a, wgs, lds, s));
 	case SA_METHOD_SW:
-		return g == 8 ? sa_launch_systolic_pk_sw(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_sw(g, klo, f16, a, wgs, lds, s);
+		return g == 8 ? sa_launch_systolic_pk_sw(g, klo, f16, a, wgs, lds, s) : (klo >= 45 ? sa_launch_systolic_pk16hi_sw(g, klo, f16, a, wgs, lds, s) : sa_launch_systolic_pk16_sw(g, klo, f16, a, wgs, lds, s));
 	default:
 		return hipErrorInvalidValue;
 	}
@@ -58,6 +60,8 @@ hipError_t sa_warm_kernels(int method, int families)
 			e = sa_warm_systolic_pk_##M();                  \
 		if (e == hipSuccess && (families & SA_WARM_PK16))       \
 			e = sa_warm_systolic_pk16_##M();                \
+		if (e == hipSuccess && (families & SA_WARM_PK16HI))     \
+			e = sa_warm_systolic_pk16hi_##M();              \
 	} while (0)
 	if (method == SA_METHOD_NW)
 		SA_WARM(nw);
