@@ -11,17 +11,23 @@ memory -- the phase the reference's metric divides by (`pairs / alignment-phase 
 phase brackets the launch/copy loop INCLUDING the device->host copies, interface/seqalign_cuda.c:182,292):
   N = 1   sa_ctx_align_host: every pair i<j scored (NW/BLOSUM62/gap 4 for the headline config) and the packed
           upper-triangular s32 vector copied into a page-locked host matrix, copies overlapping the kernels.
-  N > 1   the packed index is cut into N contiguous ranges per super-chunk (strong scaling: total work fixed);
-          every rank scores its ranges, RCCL all-gathers over xGMI assemble the packed vector on every GPU, and
-          every rank copies its 1/N share of the finished vector to its page-locked host buffer -- all inside the
-          timed step (sequencealigner_amd/distributed.py: GatherStep).
+  N > 1   strong scaling (total work fixed): the launch plan's workgroup-tiles are dealt over the N ranks by DP work
+          (sa_ctx_align_share); every rank's kernels store its scores densely for the exchange AND straight into ONE
+          page-locked packed host matrix that all ranks attach (a shared mapping under /dev/shm) -- the device->host
+          delivery of the reference's loop, without a copy pass; RCCL all-gathers over xGMI move the dense shares and
+          sa_ctx_place_shares assembles the packed s32 matrix on every GPU -- all inside the timed step
+          (sequencealigner_amd/distributed.py: TiledGatherStep).  After the timed steps every rank verifies windows of
+          the gathered matrix and its slice of the host matrix, and rank 0 checks the assembled host matrix against the
+          reference's per-column digests (tests/golden/digest_cfg2.npz).
 
 Printed JSON (rank 0): metric/value per the driver contract, plus
   device_resident -- the same pass with the result left in HBM (kernels only; >= value)
   host_boundary   -- sa_hip_align cold call (encode + upload + loop) and the `seqalign` CLI FASTA->HDF5 with -B
   roofline        -- dominant kernel vs the HBM roof, live HIP-event timing on the launch stream
   cpu_baseline    -- the reference's own CPU path (oracle/_ref, kind "reference") or our C restatement
-                     (oracle/, kind "port") timed on this host's cores on a bounded sample
+                     (oracle/, kind "port") timed on this host's cores: the whole workload when that is projected to
+                     take <= --cpu-full-seconds, else a bounded sample
+  parity          -- the CPU scores of that leg compared, untimed, with the same prefix of the host-delivered matrix
   gcups, valu     -- the bound that actually constrains this integer DP
   extra.configs   -- cfg3 (Gotoh, full size) and the cfg4 shape (SW nuc44, one GPU's worth) measured the same way
 """
