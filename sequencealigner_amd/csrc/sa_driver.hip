@@ -75,7 +75,8 @@ struct sa_ctx {
 	int64_t long_stride = 0;           /* ints per workgroup                                          */
 	int long_wgs = 0;
 	int persistent_wgs = 0;         /* workgroups of a persistent systolic launch  */
-	/* the class launches of one range run concurrently on side streams (their tails overlap) */
+	/* a range with SEVERAL launches (more than one packed bundle, s32 classes beside packed ones) runs them concurrently
+	 * on side streams forked from / joined into the caller's stream; created on first use */
 	enum { NSIDE = 8 };
 	hipStream_t side[NSIDE] = {};
 	hipEvent_t fork_ev = nullptr, join_ev[NSIDE] = {};
@@ -1130,8 +1131,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 		}
 		plan.classes.push_back(cl);
 	}
-	/* launch order: the class with the most DP work first -- the class launches of a range run side by side, and the
-	 * short ones fill the machine while the long ones taper off */
+	/* order of the classes (s32 launches; the share plans' dealing order): the class with the most DP work first */
 	std::stable_sort(plan.classes.begin(), plan.classes.end(),
 			 [](const sa_ctx::ClassLaunch &x, const sa_ctx::ClassLaunch &y) { return x.cells > y.cells; });
 	plan.start = start;
