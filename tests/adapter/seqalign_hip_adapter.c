@@ -76,6 +76,13 @@ bool cuda_memory(size_t bytes) /* src/interface/seqalign_cuda.c:71-93 */
 	return sa_hip_memory(bytes);
 }
 
+/* the reference's progress bar in its launch loop (src/interface/seqalign_cuda.c:181,286-289,293), fed by the library */
+static void hip_progress(double fraction, void *user)
+{
+	(void)user;
+	pproportc(fraction, "Aligning sequences");
+}
+
 bool cuda_align(struct input in, struct output out) /* src/interface/seqalign_cuda.c:95-296 */
 {
 	if (!device_present())
@@ -95,9 +102,14 @@ bool cuda_align(struct input in, struct output out) /* src/interface/seqalign_cu
 
 	const struct sa_input hin = { in.seqs, (struct sa_meta *)in.meta, in.max, in.num };
 	const struct sa_output hout = { out.matrix, out.seqs, out.dim, out.triangular };
+	ppercent(0, "Aligning sequences");
+	sa_hip_set_progress(hip_progress, NULL);
 	bench_align_start(); /* same bracket as the reference; sa_hip_last_align_seconds() is the loop alone */
 	const bool ok = sa_hip_align(hin, hout, &sc);
 	bench_align_end();
+	sa_hip_set_progress(NULL, NULL);
+	if (ok)
+		ppercent(100, "Aligning sequences");
 	if (!ok) {
 		perr("%s", sa_last_error()); /* CALLR-style reporting, src/interface/seqalign_cuda.c:23-30 */
 		return false;
