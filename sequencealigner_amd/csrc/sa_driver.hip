@@ -201,8 +201,13 @@ extern "C" void sa_hip_set_progress(sa_progress_fn fn, void *user)
 	g_progress_fn.store(fn);
 }
 
+/* (sa_hip_align on several devices runs one thread per slice: the first slice speaks for the job) */
+static thread_local bool t_progress_here = true;
+
 static void report_progress(double fraction)
 {
+	if (!t_progress_here)
+		return;
 	if (sa_progress_fn fn = g_progress_fn.load())
 		fn(fraction < 0 ? 0 : fraction > 1 ? 1 : fraction, g_progress_user.load());
 }
@@ -2359,7 +2364,7 @@ extern "C" int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, stru
 		ctx->out_is_host = true;
 		ok = sa_ctx_align_range(ctx, start, total, direct, d.compute) == 0;
 		ctx->out_is_host = false;
-		if (ok && g_progress_fn.load() && !ctx->prog_items.empty()) {
+		if (ok && t_progress_here && g_progress_fn.load() && !ctx->prog_items.empty()) {
 			/* Progress (the reference's pproportc in its batch loop, src/interface/seqalign_cuda.c:286-289): one launch does
 			 * the whole range here, so the host reads the launches' tile counters every 50 ms while it waits.  A counter
 			 * goes back to zero when its launch ends: fractions only ever grow. */
@@ -2516,6 +2521,7 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 			return;
 		}
 		const auto t_slice = std::chrono::steady_clock::now();
+		t_progress_here = k == 0;
 		sa_ctx *ctx = sa_ctx_create(k % nvisible, in, sc);
 		if (ctx && sa_ctx_align_host(ctx, lo, hi - lo, out, &phases[(size_t)k]) == 0)
 			oks[(size_t)k] = 1;
@@ -2529,6 +2535,7 @@ extern "C" bool sa_hip_align(struct sa_input in, struct sa_output out, const str
 			memcpy(g_breakdown, v, sizeof(v));
 		}
 		sa_ctx_destroy(ctx);
+		t_progress_here = true;
 	};
 	if (ndev == 1) {
 		run(0);
