@@ -307,13 +307,23 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         args.gpus = world
+    # SA_BENCH_ONE_GPU_REHEARSAL=1 (development): every rank on device 0 and the collective over gloo, staged through
+    # the host -- RCCL refuses two ranks on one device.  Rehearses THIS file's N > 1 code with world >= 2 on a one-GPU box
+    # (shared host matrix, trial, all-gather, verification); its timings mean nothing.
+    rehearsal = bool(os.environ.get("SA_BENCH_ONE_GPU_REHEARSAL"))
+    rdev = "cpu" if rehearsal else "cuda"  # where the small reduction tensors live
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or os.environ.get("SA_BENCH_FORCE_DIST"):  # the env switch rehearses the RCCL path on one GPU
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:  # 1-rank rehearsal without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29517"), RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     seqs, cfg = make_config(args.config, args.n)
     store = sa.SequenceStore.from_sequences(seqs)
@@ -412,9 +422,16 @@ def main():
             host = sa.PinnedMatrix(pairs, shared=shm, create=False)
         fence()
 
+    class _GlooViaHost:  # (rehearsal only: gloo moves host tensors)
+        @staticmethod
+        def all_gather_into_tensor(out, inp):
+            o = torch.empty(out.shape, dtype=out.dtype)
+            dist.all_gather_into_tensor(o, inp.cpu())
+            out.copy_(o)
+
     def make_step(c):
         if tiled:
-            return TiledGatherStep(HipShares(ctx, use16, host), store.num, world, rank, c, dist)
+            return TiledGatherStep(HipShares(ctx, use16, host), store.num, world, rank, c, _GlooViaHost if rehearsal else dist)
         return GatherStep(ctx, pairs, world, rank, c, dist, use16)
 
     # super-chunks per step: more of them hide more of the all-gather / place / host copy behind the kernels but add
@@ -431,7 +448,7 @@ def main():
             for _ in range(4):
                 trial()
             fence()
-            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tuned[c] = float(t.item()) / 4 * 1e3
             del trial
@@ -453,7 +470,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tm = ctx.timing_read()
     ctx.timing(False)
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -481,7 +498,7 @@ def main():
         for lo, hi, ho in step.host_ranges():
             if not torch.equal(step.host[ho:ho + hi - lo], step.packed[lo:hi].cpu()):
                 okflag = 0
-    t = torch.tensor([okflag], dtype=torch.int32, device="cuda")
+    t = torch.tensor([okflag], dtype=torch.int32, device=rdev)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     gather_ok = bool(t.item())
     # rank 0: the assembled host matrix against the reference's per-column digests of this workload, when the build

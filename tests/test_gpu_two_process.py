@@ -73,3 +73,22 @@ def test_two_ranks_share_one_gpu_and_one_host_matrix(tmp_path):
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "TWO_PROCESS_OK 2" in res.stdout
+
+
+def test_bench_two_rank_code_path_on_one_gpu():
+    """bench.py's own N > 1 code with world = 2 (SA_BENCH_ONE_GPU_REHEARSAL: both ranks on device 0, gloo instead of RCCL):
+    shared host matrix under /dev/shm, super-chunk trial, timed steps, per-rank verification -- the JSON line must report
+    the gathered matrix and the host matrix verified on every rank"""
+    import json
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, SA_BENCH_ONE_GPU_REHEARSAL="1", OMP_NUM_THREADS="8",
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "3000"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["config"]["gathered_and_host_result_verified_on_every_rank"] is True
