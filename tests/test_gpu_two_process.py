@@ -86,7 +86,7 @@ def test_bench_two_rank_code_path_on_one_gpu():
     env = dict(os.environ, SA_BENCH_ONE_GPU_REHEARSAL="1", OMP_NUM_THREADS="8",
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--n", "3000"]
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nseq", "3000"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
