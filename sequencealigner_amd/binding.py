@@ -393,8 +393,11 @@ class PinnedMatrix:
 
     def close(self) -> None:
         if self._registered:
-            self._lib.sa_hip_host_unregister(C.c_void_p(self.array.ctypes.data))
             self._registered = False
+            try:
+                self._lib.sa_hip_host_unregister(C.c_void_p(self.array.ctypes.data))
+            except ImportError:  # interpreter shutting down: the process's mappings go with it
+                pass
 
     __del__ = close
 
