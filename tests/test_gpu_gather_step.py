@@ -197,3 +197,28 @@ def test_share_host_matrix_must_be_page_locked(sa):
         share = torch.zeros(e, dtype=torch.int32, device="cuda")
         with pytest.raises(sa.AlignError, match="page-locked"):
             ctx.align_share(0, store.pairs, 1, 0, share.data_ptr(), False, 0, pageable.ctypes.data)
+
+
+@pytest.mark.parametrize("n", [2, 3, 9, 40])
+def test_tiled_step_on_tiny_stores(n, sa, oracle):
+    """fewer pairs than ranks, ranks without a tile, super-chunks of single columns: the step still assembles the matrix"""
+    import torch
+    from sequencealigner_amd.distributed import HipShares, TiledGatherStep
+
+    seqs = make_protein_set(n, 5, 70, 90 + n)
+    store = sa.SequenceStore.from_sequences(seqs)
+    host = sa.PinnedMatrix(store.pairs)
+    try:
+        for method, gaps in (("nw", dict(gap_pen=4)), ("sw", dict(gap_open=10, gap_extend=1))):
+            scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+            want = oracle.align(store, scoring, triangular=True)
+            with sa.Context(store, scoring, 0) as ctx:
+                for world, chunks in ((8, 1), (8, 3), (3, 2)):
+                    host.array[:] = -5
+                    step = TiledGatherStep(HipShares(ctx, True, host), store.num, world, world - 1, chunks, None)
+                    step()
+                    torch.cuda.synchronize()
+                    assert np.array_equal(step.packed.cpu().numpy(), want), (n, method, world, chunks)
+                    assert np.array_equal(host.array, want), (n, method, world, chunks, "host")
+    finally:
+        host.close()
