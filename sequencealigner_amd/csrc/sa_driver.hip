@@ -1377,7 +1377,7 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 			b.cells.assign((size_t)nranks, 0);
 			struct Part {
 				int64_t work;
-				uint32_t code;
+				uint32_t code, pair;
 			};
 			std::vector<Part> parts;
 			for (int r = 0; r < nranks; r++) {
@@ -1385,24 +1385,38 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 				for (size_t x = 0; x < b.cls.size(); x++) {
 					const auto &cl = plan.classes[(size_t)b.cls[x]];
 					const int32_t nfull = cl.ntiles - cl.npart;
+					const auto &T = tp[(size_t)cl.cls];
+					const int32_t npairs = (cl.ncols + 1) / 2;
+					int32_t pair_of_full = 0; /* (tiles ascend: the pair index only moves forward) */
 					for (int32_t t = 0; t < cl.ntiles; t++) {
+						uint32_t pair;
+						if (t < nfull) {
+							while (pair_of_full + 1 < npairs && T[(size_t)pair_of_full + 1] <= t)
+								pair_of_full++;
+							pair = (uint32_t)pair_of_full;
+						} else {
+							pair = (uint32_t)T[(size_t)(npairs + 1 + (t - nfull))];
+						}
 						if (world >= 1 && cl.owner[(size_t)t] != r)
 							continue;
 						const uint32_t code = ((uint32_t)x << SA_PK_UTILE_BITS) | (uint32_t)t;
 						const int64_t full_rows = (int64_t)SA_PK_WPB * (64 / b.g) * cl.chunk;
-						if (t < nfull && !pk_decode(cl.cls).small)
+						if (t < nfull && !pk_decode(cl.cls).small) {
 							ul.push_back(code);
-						else /* small full tiles and every partial tile: by decreasing work, after the large full tiles */
-							parts.push_back({ (t < nfull ? full_rows : (int64_t)cl.part_rows[(size_t)(t - nfull)]) * (args[x].k + 4), code });
+							ul.push_back(pair);
+						} else /* small full tiles and every partial tile: by decreasing work, after the large full tiles */
+							parts.push_back({ (t < nfull ? full_rows : (int64_t)cl.part_rows[(size_t)(t - nfull)]) * (args[x].k + 4), code, pair });
 					}
 					b.pairs[(size_t)r] += world >= 1 ? cl.rank_pairs[(size_t)r] : cl.pairs;
 					b.cells[(size_t)r] += world >= 1 ? cl.rank_cells[(size_t)r] : cl.cells;
 				}
 				std::stable_sort(parts.begin(), parts.end(), [](const Part &p, const Part &q) { return p.work > q.work; });
-				for (const Part &pt : parts)
+				for (const Part &pt : parts) {
 					ul.push_back(pt.code);
-				b.ufirst[(size_t)r + 1] = (int64_t)ul.size();
-				const int64_t n = b.ufirst[(size_t)r + 1] - b.ufirst[(size_t)r];
+					ul.push_back(pt.pair);
+				}
+				b.ufirst[(size_t)r + 1] = (int64_t)ul.size(); /* (words: two per tile) */
+				const int64_t n = (b.ufirst[(size_t)r + 1] - b.ufirst[(size_t)r]) / 2;
 				if (n > INT32_MAX) {
 					sa_set_error("packed range too large for one launch; split it into smaller ranges");
 					ok = false;

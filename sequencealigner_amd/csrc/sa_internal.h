@@ -176,7 +176,9 @@ struct SaSysArgs {
 	                           * `start`) that receives the same scores in packed order, or nullptr          */
 	int32_t nlocal;
 	const SaPkClassArgs *pkc; /* packed bundle launch: its classes; nlocal = tiles of the whole launch */
-	const uint32_t *ulist;    /* ... and its tiles in walking order (SA_PK_UTILE_BITS)                  */
+	const uint32_t *ulist;    /* ... and its tiles in walking order: two words per tile, the code (SA_PK_UTILE_BITS)
+	                           * and the tile's column pair in its class                                      */
+	int32_t tile_pair;        /* (kernel-internal: the column pair of the tile being run)                     */
 	int32_t npkc;
 	unsigned *counter;       /* [0] next unclaimed tile of this launch, [1] workgroups that have left; both zero before
 	                          * the launch and put back to zero by its last workgroup                           */
