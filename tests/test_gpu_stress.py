@@ -114,3 +114,25 @@ def test_tile_geometry(method, gaps, sa, oracle):
     check(sa, oracle, rand_seqs(rng, 200, lens, AMINO20), scoring)
     one = rand_seqs(rng, 1, [77], AMINO20)[0]
     check(sa, oracle, [one] * 70, scoring)
+
+
+def test_stamps_diagnostics_do_not_change_results(sa, oracle, tmp_path):
+    """SA_HIP_STAMPS=1 (per-tile timeline of a bundle launch) in a child process: same scores, and the
+    timeline line is printed -- the diagnostic is part of the evidence trail and must not rot"""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np, sequencealigner_amd as sa\n"
+        "from tests.synth import make_protein_set\n"
+        "from tests.oracle_binding import Oracle\n"
+        "store = sa.SequenceStore.from_sequences(make_protein_set(700, 40, 130, 5))\n"
+        "sc = sa.Scoring.from_names('ga', 'blosum62', gap_open=10, gap_extend=1)\n"
+        "got = sa.hip_align(store, sc, triangular=True)\n"
+        "assert np.array_equal(got, Oracle().align(store, sc, triangular=True, threads=8))\n"
+        "print('STAMPS_RUN_OK')\n" % str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, SA_HIP_STAMPS="1"))
+    assert res.returncode == 0 and "STAMPS_RUN_OK" in res.stdout, res.stdout[-1000:] + res.stderr[-3000:]
+    assert "[stamps] sa_k_systolic_pk_bundle<ga" in res.stderr and "active per 5% of the launch" in res.stderr
