@@ -1009,7 +1009,8 @@ static bool plan_build(sa_ctx *ctx, int64_t start, int64_t count, int world, boo
 		 * and the lowest columns of the range -- a fifth of its pairs -- in tiles a quarter of that size, which the
 		 * launch order puts last (small tiles cost more per row, +5 % at a quarter of the full size, so not everywhere). */
 		const int64_t slots = (int64_t)ctx->persistent_wgs / 8;
-		if (!ctx->env_chunk && !getenv("SA_HIP_ONE_TILE_SIZE") && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < 16 * slots) {
+		const int64_t below = getenv("SA_HIP_SMALL_BELOW") ? atoi(getenv("SA_HIP_SMALL_BELOW")) : 16; /* (experiments) */
+		if (!ctx->env_chunk && !getenv("SA_HIP_ONE_TILE_SIZE") && mine / ((int64_t)2 * SA_PK_WPB * 8 * cpk) < below * slots) {
 			int32_t big = SA_SYS_CHUNK;
 			while (big > 16 && 2 * mine / ((int64_t)2 * SA_PK_WPB * 8 * big) < 5 * slots)
 				big >>= 1;
