@@ -99,7 +99,13 @@ def self_launch(args) -> int:
     return subprocess.call(cmd, env=env)
 
 
-def cpu_baseline(seqs, cfg, target_s: float, full_s: float, got=None) -> tuple[dict, dict | None]:
+ARITH = ("packed kernels: two DP cells per 32-bit lane as u16 halves (v_pk_maximum3_f16 / v_pk_max_u16 + plain 32-bit adds), "
+         "entered only under the host's range predicate for the scoring and column class (DESIGN.md 4.2, csrc/sa_limits.cpp) and "
+         "bit-exact with the reference's s32 arithmetic; everything else runs the s32 kernels -- results are s32 either way")
+_cpu_scores = {}  # workload key -> (n, scores) of the CPU reference run, for legs that time other kernels on the same input
+
+
+def cpu_baseline(seqs, cfg, target_s: float, full_s: float, got=None, key=None) -> tuple[dict, dict | None]:
     """Reference CPU path on the same workload (pairs/s, all host cores) -> (cpu_baseline, parity).
 
     A calibration run on 600 sequences projects the whole workload; when the projection is within `full_s` seconds the
@@ -152,6 +158,8 @@ def cpu_baseline(seqs, cfg, target_s: float, full_s: float, got=None) -> tuple[d
         "gcups": store.cells() / t / 1e9,
     }
     parity = None
+    if key is not None:
+        _cpu_scores[key] = (n, scores, "reference" if use_ref else "port", bool(full))
     if got is not None:
         mism = int(np.count_nonzero(np.asarray(got[:pairs]) != scores))
         parity = {"pairs_compared": pairs, "mismatches": mism, "against": "reference" if use_ref else "port",
@@ -225,7 +233,7 @@ def time_resident_steps(ctx, packed, pairs: int, steps: int, warmup: int, torch)
     return elapsed, tm
 
 
-def cli_leg(seqs, cfg) -> dict | None:
+def cli_leg(seqs, cfg, quiet: bool = True) -> dict | None:
     """The product as a user runs it: `cli/seqalign -i x.fasta -o x.h5 ... -B` from a cold process."""
     exe = ROOT / "cli" / "seqalign"
     if not exe.exists():
@@ -237,7 +245,7 @@ def cli_leg(seqs, cfg) -> dict | None:
                 f.write(b">s%d\n" % k + s + b"\n")
         g = cfg["gaps"]
         gaps = ["-p", str(g["gap_pen"])] if "gap_pen" in g else ["-s", str(g["gap_open"]), "-e", str(g["gap_extend"])]
-        cmd = [str(exe), "-i", str(fasta), "-o", str(pathlib.Path(tmp) / "out.h5"), "-a", cfg["method"], "-m", cfg["matrix"], *gaps, "-B", "-F", "-Q"]
+        cmd = [str(exe), "-i", str(fasta), "-o", str(pathlib.Path(tmp) / "out.h5"), "-a", cfg["method"], "-m", cfg["matrix"], *gaps, "-B", "-F", *(["-Q"] if quiet else [])]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         wall = time.perf_counter() - t0
@@ -287,6 +295,34 @@ def extra_config(name: str, n, steps: int, cpu_seconds: float, cpu_full_seconds:
     out["cpu_baseline"] = base
     out["parity"] = parity
     return out
+
+
+def s32_kernels_leg(seqs, cfg, steps: int, torch, sa) -> dict:
+    """the headline workload on the s32 systolic kernels (SA_HIP_NO_PK=1: no packed-u16 classes), host-delivered, with its
+    own parity block against the CPU scores of the headline leg"""
+    import numpy as np
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    os.environ["SA_HIP_NO_PK"] = "1"  # (read when the context is created)
+    try:
+        ctx = sa.Context(store, scoring, 0)
+    finally:
+        del os.environ["SA_HIP_NO_PK"]
+    dest = sa.PinnedMatrix(store.pairs)
+    try:
+        elapsed, tm = time_host_steps(ctx, dest, steps, 1, torch)
+        sec = elapsed / steps
+        out = {"switch": "SA_HIP_NO_PK=1", "dtype": "s32", "steps": steps, "ms_per_step": sec * 1e3, "value": store.pairs / sec,
+               "unit": "pair-alignments/s", "gcups": store.cells() / sec / 1e9, "dominant_kernel": tm["kernel"], "parity": None}
+        if "cfg2" in _cpu_scores:
+            n, scores, against, whole = _cpu_scores["cfg2"]
+            k = n * (n - 1) // 2
+            out["parity"] = {"pairs_compared": k, "mismatches": int(np.count_nonzero(dest.array[:k] != scores)), "against": against,
+                             "whole_workload": whole, "compared": "host-delivered matrix of the s32 kernels vs the CPU scores of the headline leg"}
+        return out
+    finally:
+        ctx.close()
+        dest.close()
 
 
 def main():
@@ -357,7 +393,7 @@ def main():
         out = {
             "metric": "pair-alignments/sec", "value": pairs / sec, "unit": "pair-alignments/s",
             "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16x2", "arith": ARITH, "data": "synthetic",
             "config": {"workload": workload, "pairs": pairs, "cells": cells, "parallelism": "pair-range x1",
                        "timed_region": ("kernels only, result left in HBM (--device-resident-only)" if args.device_resident_only else
                                         "sa_ctx_align_host: launch + device->host copy loop into a page-locked packed host matrix "
@@ -385,12 +421,15 @@ def main():
                 "align_phase_pairs_per_s": pairs / e2e_phase if e2e_phase > 0 else None,
                 "note": "one sa_hip_align call on a pageable destination: encode + context + upload + page-locking + loop; "
                         "align_phase = its launch/copy loop only",
-                "cli": cli_leg(seqs, cfg)}
+                "cli": cli_leg(seqs, cfg),
+                # ... and as a user starts it, progress line and all (no -Q): the listener must not cost the phase anything
+                "cli_default_verbosity": {k: v for k, v in (cli_leg(seqs, cfg, quiet=False) or {}).items()
+                                          if k in ("alignment_s", "alignments_per_second", "process_wall_s", "error", "returncode")}}
         del packed
         ctx.close()
         if not args.no_cpu_baseline:
             out["cpu_baseline"], out["parity"] = cpu_baseline(seqs, cfg, args.cpu_seconds, args.cpu_full_seconds,
-                                                              dest.array if dest is not None else None)
+                                                              dest.array if dest is not None else None, key=args.config)
         if dest is not None:
             dest.close()
         if not args.no_extra and args.config == "cfg2" and args.n is None and not args.device_resident_only:
@@ -398,7 +437,12 @@ def main():
             extra = {}
             for key, (name, n) in {"cfg3": ("cfg3", None), "cfg4": ("cfg4", CFG4_SHAPE_N)}.items():
                 extra[key] = extra_config(name, n, 3, cpu_s, args.cpu_full_seconds, torch, sa, make_config)
-            out["extra"] = {"configs": extra}
+            # the length distribution the headline does not show: 8000 x U[20,190] (171 distinct lengths: few equal lengths per
+            # arranged block, so most rounds of a tile are mixed -- DESIGN.md 4.2)
+            extra["mixed"] = extra_config("mixed", None, 3, cpu_s, args.cpu_full_seconds, torch, sa, make_config)
+            out["extra"] = {"configs": extra,
+                            # the same cfg 2 step with the packed kernels switched off: the reference-width (s32) systolic kernels
+                            "s32_kernels": s32_kernels_leg(seqs, cfg, 3, torch, sa)}
         print(json.dumps(out), flush=True)
         return
 
@@ -407,13 +451,17 @@ def main():
     # xGMI); the gathered shares are widened to the reference's s32 and placed into packed order on every GPU inside
     # the timed step
     use16 = ctx.scores_fit16 and not os.environ.get("SA_BENCH_GATHER32")
-    tiled = os.environ.get("SA_BENCH_PARTITION", "tiled") != "range"  # "range": contiguous packed ranges per rank (A/B)
+    # partition of the pair space over the ranks: "tiled" (the launch plan's tiles dealt by DP work, dense shares, widen-and-
+    # place, kernels deliver to the host matrix) or "range" (contiguous packed ranges, in-place gather, every rank copies
+    # 1/N).  SA_BENCH_PARTITION fixes it; otherwise both are tried, untimed, next to the super-chunk counts.
+    forced = os.environ.get("SA_BENCH_PARTITION")
+    partitions = [forced] if forced in ("tiled", "range") else ["tiled", "range"]
 
     # the host matrix of the tiled step: ONE packed matrix for the node, a shared mapping under /dev/shm that every rank
     # attaches and page-locks (the reference's single mmap-ed result, io/output.c:55); every rank's kernels store the
     # scores that rank computed straight into it, so together the ranks fill it exactly once
     host = None
-    if tiled:
+    if "tiled" in partitions:
         shm = f"/dev/shm/sa_bench_matrix_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.bin"
         if rank == 0:
             host = sa.PinnedMatrix(pairs, shared=shm, create=True)
@@ -429,19 +477,19 @@ def main():
             dist.all_gather_into_tensor(o, inp.cpu())
             out.copy_(o)
 
-    def make_step(c):
-        if tiled:
+    def make_step(part, c):
+        if part == "tiled":
             return TiledGatherStep(HipShares(ctx, use16, host), store.num, world, rank, c, _GlooViaHost if rehearsal else dist)
-        return GatherStep(ctx, pairs, world, rank, c, dist, use16)
+        return GatherStep(ctx, pairs, world, rank, c, _GlooViaHost if rehearsal else dist, use16)
 
     # super-chunks per step: more of them hide more of the all-gather / place / host copy behind the kernels but add
     # launches; the trade depends on the fabric, so (unless --chunks fixes it) it is measured before the warmup,
     # untimed, and every rank takes the same decision from the max-over-ranks time
-    candidates = [args.chunks] if args.chunks else ([1, 2, 3] if tiled else [1, 2, 4])
+    candidates = [(part, c) for part in partitions for c in ([args.chunks] if args.chunks else ([1, 2, 3] if part == "tiled" else [1, 2]))]
     tuned = {}
     if len(candidates) > 1:
-        for c in candidates:
-            trial = make_step(c)
+        for part, c in candidates:
+            trial = make_step(part, c)
             trial(); trial()
             fence()
             t0 = time.perf_counter()
@@ -450,10 +498,13 @@ def main():
             fence()
             t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tuned[c] = float(t.item()) / 4 * 1e3
+            tuned[f"{part} x{c}"] = float(t.item()) / 4 * 1e3
             del trial
-        candidates = [min(tuned, key=tuned.get)]
-    step = make_step(candidates[0])
+            torch.cuda.empty_cache()
+        best = min(tuned, key=tuned.get)
+        candidates = [c for c in candidates if f"{c[0]} x{c[1]}" == best]
+    tiled = candidates[0][0] == "tiled"
+    step = make_step(*candidates[0])
     nchunks = step.chunks if tiled else step.sched.chunks
     my_cells = cells // world  # (tiled: the ranks' shares are balanced by DP work)
     if not tiled:
@@ -511,12 +562,31 @@ def main():
         got = column_digests(host.array, store.num)
         digest_ok = all(bool(np.array_equal(got[k], z[k])) for k in ("sum", "xor", "crc32"))
 
+    # rank 0 alone times the reference's CPU path on a bounded sample of the workload (all host cores) and compares its
+    # scores with the same prefix of the host matrix the ranks filled; the other ranks sleep on a flag file meanwhile
+    base = parity = None
+    flag = pathlib.Path(f"/dev/shm/sa_bench_cpu_done_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}")
     if rank == 0:
+        try:
+            if not args.no_cpu_baseline:
+                result = host.array if tiled else step.packed.cpu().numpy()
+                base, parity = cpu_baseline(seqs, cfg, args.cpu_seconds, 0.0, result)
+                if parity is not None:
+                    parity["compared"] = (("the ONE host matrix all ranks' kernels stored into" if tiled else "the gathered packed vector of rank 0")
+                                          + " vs the CPU scores")
+        finally:
+            flag.touch()
+    else:
+        while not flag.exists():
+            time.sleep(0.2)
+    dist.barrier()
+    if rank == 0:
+        flag.unlink(missing_ok=True)
         sec = elapsed / args.steps
         out = {
             "metric": "pair-alignments/sec", "value": pairs / sec, "unit": "pair-alignments/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "s32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u16x2", "arith": ARITH, "data": "synthetic",
             "config": {"workload": workload, "pairs": pairs, "cells": cells,
                        "parallelism": f"{'tiles of the launch plan dealt over' if tiled else 'contiguous pair ranges on'} {world} ranks + RCCL all-gather "
                                       f"({'int16 exchange, widened to s32 on device' if use16 else 's32'}), "
@@ -529,7 +599,8 @@ def main():
             "roofline": roofline_of(tm, store, args.steps, args.config, world, args.n is None),
             "valu": valu_of(method, my_cells, sec),
             "device": sa.device_name(local_rank),
-            "cpu_baseline": None,
+            "cpu_baseline": base,
+            "parity": parity,
         }
         print(json.dumps(out), flush=True)
     ctx.close()

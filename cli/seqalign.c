@@ -465,6 +465,9 @@ int main(int argc, char **argv)
 		       "  Total: %.3f sec\n",
 		       t_in, t_filter, t_align, t_out, total);
 		printf("  (device set-up and upload, outside the phases as in the reference: %.3f sec)\n", t_setup);
+		printf("  (schedule: %s)\n", sa_hip_last_align_path() == 2
+						 ? "tiles dealt over the devices, RCCL all-gather of the dense shares, placement on every device"
+						 : "every device delivers its slice of the packed index straight into the host matrix");
 		printf("Alignments per second: %.2f\n", t_align > 0 ? (double)pairs / t_align : 0.0);
 	}
 	if (pinned)

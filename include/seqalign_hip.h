@@ -96,8 +96,14 @@ bool sa_hip_memory(size_t bytes);
  * Aligns every pair i<j of `in` and fills out.matrix in the layout out.triangular
  * selects.  Caller owns in/out for the duration of the call; all device memory
  * is allocated and released inside.  Uses every visible device when
- * SA_HIP_DEVICES is unset (pair space range-partitioned, each device copies its
- * slice straight into out.matrix), or the first n with SA_HIP_DEVICES=n. */
+ * SA_HIP_DEVICES is unset, or the first n with SA_HIP_DEVICES=n.  With several
+ * devices the pair space is tiled over them (the job-wide tile list dealt by DP
+ * work), the dense shares are all-gathered over RCCL so that every device holds
+ * the whole matrix, and the host matrix is written once over all PCIe links;
+ * when RCCL cannot be bound or the matrix does not fit a device, every device
+ * delivers a contiguous slice instead (sa_hip_last_align_path tells which).
+ * Never throws and never aborts the host process: any failure -- a C++
+ * exception behind the boundary included -- is `false` + sa_last_error(). */
 bool sa_hip_align(struct sa_input in, struct sa_output out, const struct sa_scoring *sc);
 
 /* Device-assisted replacement of `bool filter(struct input *)` (src/bio/filter.c:14-89, the `-f` option):
@@ -226,11 +232,17 @@ int sa_method_gap_kind(int method);       /* enum sa_gap_kind               */
  * brackets with bench_align_start()/bench_align_end() (src/interface/seqalign_cuda.c:182,292 --
  * uploads, allocations and context set-up are outside it, the device->host copies inside). */
 double sa_hip_last_align_seconds(void);
+/* Which schedule the last successful sa_hip_align() took: 1 = every device delivers a contiguous slice of the packed
+ * index straight into the host matrix (one device: the whole range); 2 = tile-interleaved dense shares + RCCL
+ * all-gather + placement on every device, then delivery (several devices); 0 = no call yet. */
+int sa_hip_last_align_path(void);
 
 /* Progress of a running sa_hip_align / sa_ctx_align_host, the reference's ppercent / pproportc side channel
- * (src/interface/seqalign_cuda.c:181,286-289,293): fn(fraction in [0,1], user) is called from the calling thread while it
- * waits for the device -- per batch on the batched paths, every 50 ms from the launches' tile counters on the
- * single-launch path.  NULL (the default) reports nothing and polls nothing. */
+ * (src/interface/seqalign_cuda.c:181,286-289,293): fn(fraction in [0,1], user) is called while the host waits for the
+ * device -- per batch on the batched paths, every 50 ms from the launches' tile counters on the single-launch path --
+ * from the calling thread when one device is used, from ONE worker thread of the library (the first slice's) when
+ * sa_hip_align spreads the job over several: calls never overlap, but the callback must not assume the caller's thread.
+ * NULL (the default) reports nothing and polls nothing; the polling waits in 250 us slices and never past completion. */
 typedef void (*sa_progress_fn)(double fraction, void *user);
 void sa_hip_set_progress(sa_progress_fn fn, void *user);
 

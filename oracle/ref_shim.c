@@ -115,3 +115,40 @@ int ref_filter(uchar *seqs, struct meta *meta, s32 *num, s32 *max)
 	*max = in.max;
 	return in.num;
 }
+
+/* A stripe of whole columns [j_lo, j_hi) of the all-vs-all run, each column through the reference's per-pair kernel
+ * exactly as its driver calls it (src/bio/align.c:44-58: column sequence j indexed once through SEQ_LUT, then
+ * ALIGN->method(len_j, len_i, seq_i, ind_j, table) for every i < j).  out receives column j_lo's j_lo scores, then
+ * column j_lo+1's, ...: the packed layout of src/io/output.c:83 restricted to the stripe.  Used by
+ * tools/make_digests.py for the full-size cfg 4 / cfg 5 stripes, where running align() over the whole matrix would
+ * take hours of CPU. */
+int ref_columns(const uchar *seqs, const struct meta *meta, s32 num, s32 max, s32 j_lo, s32 j_hi, s32 *out)
+{
+	if (j_lo < 1 || j_hi > num || j_lo > j_hi)
+		return 1;
+	TABLE_SIZE = (size_t)(max + 1) * (size_t)(max + 1);
+	const size_t mult = ALIGN->gap == GAP_AFFINE ? 3 : 1;
+	int failed = 0;
+#pragma omp parallel
+	{
+		s32 *table = malloc(sizeof(*table) * TABLE_SIZE * mult);
+		s32 *ind = malloc(sizeof(*ind) * (size_t)max);
+		if (!table || !ind)
+			failed = 1;
+#pragma omp barrier
+		if (!failed) {
+#pragma omp for schedule(dynamic) collapse(1)
+			for (s32 j = j_lo; j < j_hi; j++) {
+				const struct meta m1 = meta[j];
+				for (s32 k = 0; k < m1.len; k++)
+					ind[k] = SEQ_LUT[seqs[m1.off + k]];
+				s32 *col = out + ((size_t)j * (size_t)(j - 1) / 2 - (size_t)j_lo * (size_t)(j_lo - 1) / 2);
+				for (s32 i = 0; i < j; i++)
+					col[i] = ALIGN->method(m1.len, meta[i].len, seqs + meta[i].off, ind, table);
+			}
+		}
+		free(ind);
+		free(table);
+	}
+	return failed;
+}

@@ -26,6 +26,7 @@ from .binding import (  # noqa: F401
     device_count,
     device_name,
     last_align_breakdown,
+    last_align_path,
     last_align_seconds,
     hip_align,
     hip_filter,
@@ -39,6 +40,6 @@ from .binding import (  # noqa: F401
 )
 
 __all__ = [
-    "AlignError", "Context", "PinnedMatrix", "Scoring", "SequenceStore", "device_count", "device_name", "last_align_breakdown", "last_align_seconds", "hip_align", "hip_filter",
+    "AlignError", "Context", "PinnedMatrix", "Scoring", "SequenceStore", "device_count", "device_name", "last_align_breakdown", "last_align_path", "last_align_seconds", "hip_align", "hip_filter",
     "hip_memory", "library_path", "load_library", "matrix_names", "method_names", "pair_count", "set_progress",
 ]

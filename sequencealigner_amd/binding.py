@@ -52,6 +52,7 @@ ABI_SYMBOLS = (
     "sa_abi_version",
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
     "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown", "sa_ctx_leave_room", "sa_hip_set_progress",
+    "sa_hip_last_align_path",
 )
 
 
@@ -139,6 +140,7 @@ def load_library() -> C.CDLL:
     lib.sa_last_error.restype = C.c_char_p
     lib.sa_abi_version.restype = C.c_int
     lib.sa_hip_last_align_seconds.restype = C.c_double
+    lib.sa_hip_last_align_path.restype = C.c_int
     lib.sa_ctx_align_host.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _Output, C.POINTER(C.c_double)]
     lib.sa_ctx_align_host.restype = C.c_int
     lib.sa_hip_host_register.argtypes = [C.c_void_p, C.c_size_t]
@@ -172,6 +174,12 @@ def device_count() -> int:
 def last_align_seconds() -> float:
     """launch/copy phase of the last hip_align call (the reference's bench_align bracket, seqalign_cuda.c:182,292)"""
     return float(load_library().sa_hip_last_align_seconds())
+
+
+def last_align_path() -> str:
+    """schedule of the last hip_align call: "slices" (every device delivers a contiguous slice; one device: the whole
+    range) or "gather" (dense shares + RCCL all-gather + placement on every device)"""
+    return {0: "none", 1: "slices", 2: "gather"}[int(load_library().sa_hip_last_align_path())]
 
 
 def last_align_breakdown() -> dict:

@@ -5,7 +5,8 @@
 #include <cstring>
 #include <strings.h>
 
-#include "sa_internal.h"
+#include <cstdarg>
+#include "sa_shapes.h"
 #include "sa_matrix_tables.inc"
 
 static thread_local char g_err[1024] = "";

@@ -10,7 +10,7 @@ GOLDEN_DIR = pathlib.Path(__file__).resolve().parent / "golden"
 
 
 def golden_cases() -> list[str]:
-    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith(("filter_", "digest_")))
+    return sorted(p.stem for p in GOLDEN_DIR.glob("*.npz") if not p.stem.startswith(("filter_", "digest_", "stripes_")))
 
 
 def load_case(name: str):

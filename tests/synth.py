@@ -74,6 +74,8 @@ CONFIGS = {
     "cfg2": dict(kind="protein", n=10_000, lo=80, hi=120, seed=2, method="nw", matrix="blosum62", gaps=dict(gap_pen=4)),
     "cfg3": dict(kind="protein", n=10_000, lo=80, hi=120, seed=2, method="ga", matrix="blosum62", gaps=dict(gap_open=10, gap_extend=1)),
     "cfg4": dict(kind="dna", n=50_000, lo=120, hi=180, seed=4, method="sw", matrix="nuc44", gaps=dict(gap_open=10, gap_extend=1)),
+    # not a BASELINE config: the mixed-length leg of bench.py (few equal lengths per arranged block)
+    "mixed": dict(kind="protein", n=8_000, lo=20, hi=190, seed=7, method="nw", matrix="blosum62", gaps=dict(gap_pen=4)),
     "cfg5": dict(kind="protein", n=100_000, lo=96, hi=144, seed=5, method="nw", matrix="blosum62", gaps=dict(gap_pen=4), dup=0.10),
 }
 

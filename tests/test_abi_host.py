@@ -121,3 +121,62 @@ def test_no_device_fails_loudly(sa):
     with pytest.raises(sa.AlignError):
         sa.Context(st, sa.Scoring.from_names("nw", "blosum62", gap_pen=4))
     assert sa.hip_memory(1 << 20) is False
+
+
+_ALLOC_FAILURE = r"""
+import ctypes as C, resource, sys
+import numpy as np
+import sequencealigner_amd as sa
+lib = sa.load_library()
+n = 40_000_000                                  # sa_pairs_partition needs two int64 prefix arrays: 640 MB
+meta = np.zeros((n, 2), np.int32); meta[:, 1] = 50
+bounds = (C.c_int64 * 3)()
+vm = int(next(l for l in open("/proc/self/status") if l.startswith("VmSize")).split()[1]) * 1024
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+resource.setrlimit(resource.RLIMIT_AS, (vm + (300 << 20), hard))   # soft limit only: it can be lifted again
+rc = lib.sa_pairs_partition(meta.ctypes.data, n, 2, bounds)   # std::bad_alloc behind the extern "C" boundary
+print("rc", rc, "| error:", lib.sa_last_error().decode())
+cells = lib.sa_pairs_cells(meta.ctypes.data, n, 0, 10)
+print("cells", cells, "| error:", lib.sa_last_error().decode())
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+rc = lib.sa_pairs_partition(meta.ctypes.data, n, 2, bounds)   # ... and the library is still usable afterwards
+print("again", rc, bounds[1] > 0, bounds[2] == n * (n - 1) // 2)
+"""
+
+
+def test_allocation_failure_behind_the_abi_is_an_error_not_an_abort():
+    """The reference's failure model is `perr` + `return false` (src/interface/seqalign_cuda.c:23-30).  The host side of
+    this library is C++: a std::bad_alloc (or any other exception) raised behind an extern "C" entry point must come back
+    the same way -- failure value + sa_last_error() -- never as std::terminate / SIGABRT of the host process.  Forced
+    here with RLIMIT_AS in a child process: the two prefix arrays of sa_pairs_partition cannot be allocated."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-c", _ALLOC_FAILURE], capture_output=True, text=True, timeout=600, cwd=str(ROOT))
+    assert res.returncode == 0, f"child died with {res.returncode} (an abort is -6):\n{res.stdout}\n{res.stderr[-3000:]}"
+    lines = res.stdout.strip().splitlines()
+    assert lines[0].startswith("rc 1 | error: sa_pairs_partition: out of host memory"), res.stdout
+    assert lines[1].startswith("cells -1 | error: sa_pairs_cells: out of host memory"), res.stdout
+    assert lines[2] == "again 0 True True", res.stdout
+
+
+def test_every_entry_point_with_a_body_sits_behind_the_exception_barrier():
+    """source-level guard: every extern "C" definition in csrc/ either runs its body through sa_guard / sa_guard_void or is
+    on the short list of entry points that cannot throw (no allocation, no container, no std::string)"""
+    nothrow = {"sa_last_error", "sa_abi_version", "sa_matrix_count", "sa_matrix_name", "sa_matrix_is_nucleotide", "sa_matrix_load",
+               "sa_method_parse", "sa_method_name", "sa_method_gap_kind", "sa_hip_device_count", "sa_hip_device_name",
+               "sa_ctx_pairs", "sa_ctx_scores_fit16", "sa_ctx_leave_room", "sa_hip_widen16", "sa_ctx_expand_full",
+               "sa_hip_set_progress", "sa_hip_last_align_seconds", "sa_hip_last_align_path", "sa_hip_last_align_breakdown",
+               "sa_hip_host_register", "sa_hip_host_unregister", "sa_ctx_destroy", "sa_ctx_timing"}
+    guarded, plain = set(), set()
+    for src in sorted((ROOT / "sequencealigner_amd" / "csrc").glob("*")):
+        if src.suffix not in (".hip", ".cpp"):
+            continue
+        text = src.read_text()
+        for m in re.finditer(r'extern "C" [^\n;{]*?\b(sa_[a-z0-9_]+)\s*\([^;{]*\)\s*\{', text, flags=re.S):
+            body = text[m.end():text.index("\n}\n", m.end())]
+            (guarded if "sa_guard" in body else plain).add(m.group(1))
+    assert guarded >= {"sa_hip_align", "sa_hip_memory", "sa_hip_filter", "sa_ctx_create", "sa_ctx_align_range", "sa_ctx_align_range16",
+                       "sa_ctx_align_host", "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_ctx_timing_read",
+                       "sa_pairs_cells", "sa_pairs_partition"}, guarded
+    assert plain <= nothrow, f"entry points without a barrier that are not on the no-throw list: {sorted(plain - nothrow)}"
+    assert sorted(guarded | plain) == declared_symbols()

@@ -19,8 +19,10 @@ def built_cli():
         subprocess.check_call(["make", "-s", "-C", str(ROOT / "cli")])
 
 
-def run(*args, check=True):
-    res = subprocess.run([str(CLI), *map(str, args)], capture_output=True, text=True, timeout=600)
+def run(*args, check=True, env=None):
+    import os
+    res = subprocess.run([str(CLI), *map(str, args)], capture_output=True, text=True, timeout=600,
+                         env=None if env is None else dict(os.environ, **env))
     if check:
         assert res.returncode == 0, res.stdout + res.stderr
     return res
@@ -44,6 +46,24 @@ def test_cli_matches_reference_golden(case, flags, tmp_path):
     write_fasta(fasta, seqs)
     res = run("-i", fasta, "-o", out, *flags, "-F", "-B")
     assert "Alignments per second" in res.stdout
+    assert np.array_equal(h5_matrix(out, store.num), tri_to_full(expected, store.num))
+    assert h5_sequences(out) == seqs
+
+
+@pytest.mark.parametrize("case,flags", [
+    ("cfg1_nw_blosum62_p4", ["-a", "nw", "-m", "blosum62", "-p", 4]),
+    ("p64_sw_blosum62_10_1", ["-a", "sw", "-m", "blosum62", "-s", 10, "-e", 1, "-z", 3]),
+])
+def test_cli_through_the_all_gather_path(case, flags, tmp_path):
+    """the tool on the schedule it takes with several GPUs -- dense shares, RCCL all-gather, placement, shells to the host
+    (csrc/sa_gather.hip) -- forced onto the one device of this box (a one-rank communicator): the HDF5 it writes is the
+    reference's golden, and -B names the schedule"""
+    store, scoring, expected, _ = load_case(case)
+    seqs = [store.sequence(k) for k in range(store.num)]
+    fasta, out = tmp_path / "in.fasta", tmp_path / "out.h5"
+    write_fasta(fasta, seqs)
+    res = run("-i", fasta, "-o", out, *flags, "-F", "-B", env={"SA_HIP_GATHER": "1"})
+    assert "RCCL all-gather" in res.stdout, res.stdout
     assert np.array_equal(h5_matrix(out, store.num), tri_to_full(expected, store.num))
     assert h5_sequences(out) == seqs
 

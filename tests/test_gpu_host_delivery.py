@@ -124,3 +124,34 @@ def test_progress_side_channel(sa, oracle):
     assert direct, "no progress was reported during a ~100 ms launch"
     for fr in (direct, seen):
         assert all(0.0 <= f <= 1.0 for f in fr) and all(a <= b for a, b in zip(fr, fr[1:]))
+
+
+def test_progress_polling_stays_out_of_the_timed_phase(sa):
+    """A listener must not change what it observes: the phase (the reference's bench_align bracket) of a SHORT job with a
+    progress callback set stays within ~1.5 ms of the phase without one.  (Round 3's poll slept 50 ms inside the phase:
+    cfg 2's 15 ms loop reported -- and took -- 50 ms whenever the CLI showed its progress line.)"""
+    from tests.synth import make_config
+    seqs, cfg = make_config("cfg2", 6000)  # ~5 ms of NW
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    dest = sa.PinnedMatrix(store.pairs)
+    full = sa.PinnedMatrix(store.num * store.num)
+    try:
+        with sa.Context(store, scoring, 0) as ctx:
+            def best(matrix, triangular):
+                return min(ctx.align_host(matrix, triangular=triangular) for _ in range(7))
+            ctx.align_host(dest.array, triangular=True)
+            ctx.align_host(full.array, triangular=False)
+            quiet, quiet_full = best(dest.array, True), best(full.array, False)
+            calls = []
+            sa.set_progress(calls.append)
+            try:
+                loud, loud_full = best(dest.array, True), best(full.array, False)
+            finally:
+                sa.set_progress(None)
+        assert loud < quiet + 1.5e-3, f"direct stores: {quiet * 1e3:.2f} ms without a listener, {loud * 1e3:.2f} ms with one"
+        assert loud_full < quiet_full + 2.5e-3, f"shells: {quiet_full * 1e3:.2f} ms without a listener, {loud_full * 1e3:.2f} ms with one"
+        assert all(0.0 <= f <= 1.0 for f in calls)
+    finally:
+        dest.close()
+        full.close()
