@@ -73,7 +73,7 @@ int main(int argc, char **argv)
 	sc.gap_opn = gap_arg(argv[7]);
 	sc.gap_ext = gap_arg(argv[8]);
 	struct sa_host_store store;
-	if (sa_host_load(argv[9], sc.lut, 1, -1, 0, &store))
+	if (sa_host_load(argv[9], sc.lut, sc.gap_pen, -1, 0, &store)) /* (gap in its stored, negated form: src/io/input.c:15-19) */
 		DIE("%s", sa_host_error());
 	const int64_t pairs = (int64_t)store.in.num * (store.in.num - 1) / 2;
 

@@ -28,7 +28,7 @@ torch.cuda.synchronize(); t_full = (time.perf_counter() - t0) / 10
 print(f"{cfgname} whole range on one GPU: {t_full*1e3:.3f} ms  -> ideal share at world {world}: {t_full/world*1e3:.3f} ms")
 ranges = column_chunks(store.num, chunks)
 host = sa.PinnedMatrix(store.pairs)
-for rank in (0, world // 2, world - 1):
+for rank in (0, world // 2, world - 1, 0):  # (rank 0 twice: the first measurement after the idle set-up runs on ramping clocks)
     if mode == "range":
         sched = ChunkedGather(store.pairs, world, rank, chunks)
         buf = torch.empty(store.pairs // world + 16, dtype=torch.int32, device="cuda")
@@ -41,7 +41,7 @@ for rank in (0, world // 2, world - 1):
         def step():
             for (lo, cnt), b in zip(ranges, bufs):
                 ctx.align_share(lo, cnt, world, rank, b.data_ptr(), True, s, host.ptr)
-    for _ in range(3): step()
+    for _ in range(10): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
     torch.cuda.synchronize(); t = (time.perf_counter() - t0) / 20
