@@ -10,6 +10,7 @@ if str(ROOT) not in sys.path:
 
 
 # a SIGABRT raised anywhere in the test process (runtime, allocator, library) leaves its C backtrace here
+(ROOT / "gpurun_out").mkdir(exist_ok=True)  # (open(O_CREAT) in a signal handler creates files, not directories)
 os.environ.setdefault("SA_HIP_ABORT_TRACE", str(ROOT / "gpurun_out" / "abort_backtrace.txt"))
 
 
