@@ -20,7 +20,7 @@ SaEnv sa_env_read()
 	e.no_pk = flag("SA_HIP_NO_PK");
 	e.no_pk16 = flag("SA_HIP_NO_PK16");
 	e.no_sort = flag("SA_HIP_NO_SORT");
-	e.serial_classes = flag("SA_HIP_SERIAL_CLASSES");
+	e.concurrent_classes = flag("SA_HIP_CONCURRENT_CLASSES");
 	e.one_tile_size = flag("SA_HIP_ONE_TILE_SIZE");
 	e.chunk = number("SA_HIP_CHUNK", 0, 1, 32);
 	e.pk_wgs = number("SA_HIP_PK_WGS", 0, 0, 1 << 20);

@@ -285,8 +285,11 @@ static int align_range_launches(sa_ctx *ctx, int64_t start, int64_t count, int32
 	};
 
 	/* Systolic streaming kernels.  Packed classes: one persistent launch per BUNDLE (normally one for the whole range).
-	 * s32 classes: one persistent launch per class.  A single launch goes to the caller's stream; several go to side
-	 * streams forked from / joined back into it so that they run concurrently. */
+	 * s32 classes: one persistent launch per class.  Several launches of a range run ONE AFTER THE OTHER on the caller's
+	 * stream, the bundle of the largest K first: every one of them fills the chip by itself, and side by side (round 3: side
+	 * streams forked from / joined into the caller's) their workgroups -- different LDS sizes, different code -- crowd each
+	 * other out of the CUs: cfg 4's two bundles 49.6 -> 46.1 ms, cfg 5's 30.8 -> 29.7 ms, three bundles of a mixed-length
+	 * store 12.35 -> 11.54 ms (profiles/r04_bundles_side_by_side_vs_serial.txt).  SA_HIP_CONCURRENT_CLASSES=1: side by side. */
 	const int rk = share ? rank : 0;
 	struct Item {
 		int bundle, cls; /* index into the plan's bundles, or into its classes (s32 classes) */
@@ -303,7 +306,7 @@ static int align_range_launches(sa_ctx *ctx, int64_t start, int64_t count, int32
 			continue;
 		items.push_back({ -1, (int)ci });
 	}
-	const bool fan_out = items.size() > 1 && !ctx->env.serial_classes;
+	const bool fan_out = items.size() > 1 && ctx->env.concurrent_classes;
 	unsigned *const counters = ctx->d_counters + slot * sa_ctx::COUNTERS_PER_SLOT;
 	if (fan_out) {
 		if (!ctx->fork_ev) {

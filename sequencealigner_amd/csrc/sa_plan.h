@@ -92,7 +92,7 @@ int sa_systolic_class_for(int32_t n);
 bool sa_arranged_exists(int32_t num, const SaArrKey &key);
 /* The arranged copies offered to the tiles of one packed class (largest block first); returns how many, lv[l].block = 0
  * beyond.  host_out: scores (also) leave straight to host memory -- a block is then one tile (row-order epilogue). */
-int sa_pk_arranged_keys(const SaPlanInputs &in, int pk_g, int32_t chunk_pk, bool host_out, SaArrKey (&lv)[SA_PK_SORT_LEVELS]);
+int sa_pk_arranged_keys(const SaPlanInputs &in, int pk_g, int pk_k, int32_t chunk_pk, bool host_out, SaArrKey (&lv)[SA_PK_SORT_LEVELS]);
 /* The permutation of one arranged copy: rowmap[position] = row (DESIGN 4.2 "arranged row streams") */
 void sa_arrange_rows(const sa_meta *meta, int32_t num, const SaArrKey &key, std::vector<int32_t> &rowmap);
 

@@ -49,7 +49,7 @@ static TileGeo tile_geo(const SaHostPlan &pl, const SaHostClass &cl, int32_t t)
 	};
 	if (cl.cls >= SA_PK_CLASS0) {
 		const SaPkCls pc = sa_pk_decode(cl.cls);
-		const int32_t rows = SA_PK_WPB * (64 / pc.g) * cl.chunk;
+		const int32_t rows = sa_pk_wpb(pc.g, pc.k) * (64 / pc.g) * cl.chunk;
 		const int32_t npairs = (cl.ncols + 1) / 2, nfull = cl.tprefix[(size_t)npairs];
 		int32_t lo;
 		if (t < nfull)

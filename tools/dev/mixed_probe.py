@@ -36,8 +36,8 @@ def run(tag, seqs, env=None):
 
 
 run("cfg2-like U[80,120] x 8000", make_protein_set(8000, 80, 120, 2))
-run("U[20,190] x 8000 (three bundles side by side)", make_protein_set(8000, 20, 190, 7))
-run("U[20,190] x 8000, bundles one after the other", make_protein_set(8000, 20, 190, 7), {"SA_HIP_SERIAL_CLASSES": "1"})
+run("U[20,190] x 8000 (three bundles one after the other)", make_protein_set(8000, 20, 190, 7))
+run("U[20,190] x 8000, bundles side by side", make_protein_set(8000, 20, 190, 7), {"SA_HIP_CONCURRENT_CLASSES": "1"})
 run("U[20,190] x 8000, store order (no arrangement)", make_protein_set(8000, 20, 190, 7), {"SA_HIP_NO_SORT": "1"})
 run("U[20,64] x 8000   (K 3..8)", make_protein_set(8000, 20, 64, 7))
 run("U[65,128] x 8000  (K 9..16)", make_protein_set(8000, 65, 128, 7))
@@ -45,3 +45,7 @@ run("U[129,190] x 8000 (K 17..24)", make_protein_set(8000, 129, 190, 7))
 run("U[100,100] x 8000 (one class, all rounds pure)", make_protein_set(8000, 100, 100, 7))
 run("U[57,64] x 8000   (K 8 only)", make_protein_set(8000, 57, 64, 7))
 run("U[185,192] x 8000 (K 24 only)", make_protein_set(8000, 185, 192, 7))
+# two bundles (cfg 4 / cfg 5 length ranges): side by side vs one after the other
+for tag, lo, hi in (("U[120,180] x 12000 (cfg 4 lengths, K 15..23)", 120, 180), ("U[96,144] x 12000 (cfg 5 lengths, K 12..18)", 96, 144)):
+    run(tag + " one after the other", make_protein_set(12000, lo, hi, 4))
+    run(tag + " side by side", make_protein_set(12000, lo, hi, 4), {"SA_HIP_CONCURRENT_CLASSES": "1"})
