@@ -506,55 +506,6 @@ size_t sa_host_hdf5_chunk_dim(size_t dim)
 	return c < dim ? c : dim;
 }
 
-/* The tiles of an uncompressed chunked N x N dataset, filled in place through a shared file mapping by all cores: tile
- * (cy, cx) holds rows [cy c, cy c + c) x columns [cx c, cx c + c) row-major, zero beyond the matrix.  `matrix` is the full
- * N x N matrix or the packed triangle (pair i<j at j(j-1)/2+i; the diagonal is written as 0). */
-static int fill_raw_tiles(const char *path, const haddr_t *addr, size_t nc, size_t chunk, size_t dim, const int32_t *matrix,
-			  bool triangular)
-{
-	const int fd = open(path, O_RDWR);
-	if (fd < 0)
-		return fail("Failed to reopen HDF5 file: %s", path);
-	haddr_t lo = addr[0], hi = addr[0];
-	for (size_t c = 0; c < nc * nc; c++) {
-		lo = addr[c] < lo ? addr[c] : lo;
-		hi = addr[c] > hi ? addr[c] : hi;
-	}
-	const size_t tile_bytes = chunk * chunk * 4, span = (size_t)(hi - lo) + tile_bytes;
-	struct stat sb;
-	if (fstat(fd, &sb) || (haddr_t)sb.st_size < hi + tile_bytes) { /* (allocated but never written: make the tail real) */
-		if (ftruncate(fd, (off_t)(hi + tile_bytes))) {
-			close(fd);
-			return fail("Failed to size HDF5 file: %s", path);
-		}
-	}
-	uint8_t *map = mmap(NULL, span, PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)lo);
-	close(fd);
-	if (map == MAP_FAILED)
-		return fail("Failed to map HDF5 file: %s", path);
-	const size_t bands = nc * nc * chunk; /* one tile row = one unit of work: 16 KB at chunk 4096 */
-#pragma omp parallel for schedule(static, 64)
-	for (size_t u = 0; u < bands; u++) {
-		const size_t c = u / chunk, r = u % chunk, cy = c / nc, cx = c % nc;
-		const size_t i = cy * chunk + r, j0 = cx * chunk;
-		int32_t *dst = (int32_t *)(map + (size_t)(addr[c] - lo)) + r * chunk;
-		const size_t w = i < dim ? (j0 + chunk <= dim ? chunk : dim - j0) : 0; /* columns of this tile row inside the matrix */
-		if (!triangular) {
-			if (w)
-				memcpy(dst, matrix + i * dim + j0, w * sizeof(int32_t));
-		} else {
-			for (size_t q = 0; q < w; q++) {
-				const size_t j = j0 + q;
-				dst[q] = j < i ? matrix[i * (i - 1) / 2 + j] : j == i ? 0 : matrix[j * (j - 1) / 2 + i];
-			}
-		}
-		if (w < chunk)
-			memset(dst + w, 0, (chunk - w) * sizeof(int32_t));
-	}
-	munmap(map, span);
-	return 0;
-}
-
 int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const int32_t *matrix, bool triangular,
 		       unsigned compression)
 {
@@ -603,40 +554,12 @@ int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const in
 		if (compression)
 			H5Pset_deflate(plist, compression);
 	}
-	/* Uncompressed chunks are raw row-major tiles in the file: allocate them all at creation, ask the library where each one
-	 * lies, close the file and fill the tiles through a shared mapping from every core (below).  libhdf5 writes them from one
-	 * thread through write(), which serialises on the file: 0.22 s of a 0.5 s cold run for cfg 2's 400 MB (576 MB of tiles). */
-	const bool raw_tiles = dim > 256 && !compression && !getenv("SA_HOST_NO_RAW_TILES");
-	if (raw_tiles) {
-		H5Pset_alloc_time(plist, H5D_ALLOC_TIME_EARLY);
-		H5Pset_fill_time(plist, H5D_FILL_TIME_NEVER);
-	}
 	hid_t mset = H5Dcreate2(file, "/similarity_matrix", H5T_STD_I32LE, mspace, H5P_DEFAULT, plist, H5P_DEFAULT);
 	H5Pclose(plist);
 	H5Sclose(mspace);
 	if (mset < 0) {
 		H5Fclose(file);
 		return fail("Failed to create HDF5 dataset for Similarity Matrix");
-	}
-	if (raw_tiles) {
-		const size_t nc = (dim + chunk - 1) / chunk;
-		haddr_t *addr = malloc(sizeof(*addr) * nc * nc);
-		bool ok = addr != NULL;
-		for (size_t c = 0; ok && c < nc * nc; c++) {
-			hsize_t at[2] = { (c / nc) * chunk, (c % nc) * chunk }, bytes = 0;
-			unsigned mask = 0;
-			ok = H5Dget_chunk_info_by_coord(mset, at, &mask, &addr[c], &bytes) >= 0 && addr[c] != HADDR_UNDEF &&
-			     bytes == (hsize_t)chunk * chunk * 4 && addr[c] % 4096 == 0;
-		}
-		H5Dclose(mset);
-		H5Fclose(file);
-		if (ok) {
-			rc = fill_raw_tiles(path, addr, nc, chunk, dim, matrix, triangular);
-			free(addr);
-			return rc;
-		}
-		free(addr);
-		return fail("Failed to locate the chunks of the Similarity Matrix in the HDF5 file");
 	}
 	if (!triangular) {
 		st = H5Dwrite(mset, H5T_NATIVE_INT32, H5S_ALL, H5S_ALL, H5P_DEFAULT, matrix);

@@ -107,35 +107,10 @@ def test_hdf5_roundtrip_full_and_triangular(host, tmp_path, amino_lut):
     assert np.array_equal(h5_matrix(path, n), tri_to_full(tri, n))
     hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
     assert "CHUNKED ( 256, 256 )" in hdr and "DEFLATE { LEVEL 6 }" in hdr and "H5T_STD_I32LE" in hdr
-    # chunked, uncompressed: the tiles are filled in place through a shared mapping by all cores (cli/sa_host.c:
-    # fill_raw_tiles) -- 2 x 2 tiles of 512 with ragged edges, packed and full input, and the library's own writer as the
-    # cross-check (SA_HOST_NO_RAW_TILES)
-    n = 700
-    tri = rng.integers(-500, 500, n * (n - 1) // 2, dtype=np.int32)
-    seqs700 = [bytes(rng.choice(list(b"ARNDCQEG"), 4).astype(np.uint8)) for _ in range(n)]
-    want = tri_to_full(tri, n)
-    for packed in (True, False):
-        path = tmp_path / f"raw_{int(packed)}.h5"
-        host.write_hdf5(path, seqs700, amino_lut, tri if packed else want, packed, 0)
-        assert np.array_equal(h5_matrix(path, n), want)
-        assert h5_sequences(path) == seqs700
-        hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
-        assert "CHUNKED ( 512, 512 )" in hdr and "DEFLATE" not in hdr
-    import os
-    os.environ["SA_HOST_NO_RAW_TILES"] = "1"
-    try:
-        path = tmp_path / "lib_writer.h5"
-        host.write_hdf5(path, seqs700, amino_lut, tri, True, 0)
-    finally:
-        del os.environ["SA_HOST_NO_RAW_TILES"]
-    assert np.array_equal(h5_matrix(path, n), want)
-    if H5DIFF.exists():
-        res = subprocess.run([str(H5DIFF), str(path), str(tmp_path / "raw_1.h5")], capture_output=True, text=True)
-        assert res.returncode == 0, res.stdout + res.stderr
 
 
 @pytest.mark.skipif(not (ref_available() and H5DIFF.exists()), reason="needs oracle/_ref and h5diff")
-@pytest.mark.parametrize("n,z", [(100, 0), (300, 6), (300, 0), (700, 0)])  # (N > 256 uncompressed: tiles filled through a mapping)
+@pytest.mark.parametrize("n,z", [(100, 0), (300, 6)])
 def test_hdf5_equals_reference_writer(host, tmp_path, amino_lut, sa, oracle, n, z):
     from tests.synth import make_protein_set
     seqs = make_protein_set(n, 5, 20, 13)

@@ -124,3 +124,26 @@ def test_frame_budget_follows_the_shortest_sequence(method, gaps, shortest, sa, 
     store = sa.SequenceStore.from_sequences(seqs)
     scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
     assert np.array_equal(sa.hip_align(store, scoring, triangular=True), oracle.align(store, scoring, triangular=True, threads=8))
+
+
+def test_several_launches_one_after_the_other_or_side_by_side(sa, oracle, monkeypatch):
+    """a store whose columns need three packed bundles, s32 classes and the strip-mined launch: the launches of one range run
+    one after the other on the caller's stream (default) or side by side on side streams (SA_HIP_CONCURRENT_CLASSES,
+    round 3's schedule) -- the same scores either way, whole and in ranges that cut columns"""
+    import torch
+    lens = list(range(3, 200, 7)) + [220, 330, 520, 700, 900, 1024, 1100, 1500] + [40] * 300 + [150] * 200
+    seqs = [seq_of(n, 5000 + i) for i, n in enumerate(lens)]
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names("ga", "blosum62", gap_open=10, gap_extend=1)
+    want = oracle.align(store, scoring, triangular=True)
+    for concurrent in (False, True):
+        if concurrent:
+            monkeypatch.setenv("SA_HIP_CONCURRENT_CLASSES", "1")
+        with sa.Context(store, scoring, 0) as ctx:
+            out = torch.empty(ctx.pairs, dtype=torch.int32, device="cuda")
+            st = torch.cuda.current_stream().cuda_stream
+            cuts = [0, 777, ctx.pairs // 3, ctx.pairs // 3 + 1, ctx.pairs - 5, ctx.pairs]
+            for a, b in zip(cuts, cuts[1:]):
+                ctx.align_range(a, b - a, out.data_ptr() + 4 * a, st)
+            torch.cuda.synchronize()
+            assert np.array_equal(out.cpu().numpy(), want), "side by side" if concurrent else "one after the other"
