@@ -107,10 +107,34 @@ def test_hdf5_roundtrip_full_and_triangular(host, tmp_path, amino_lut):
     assert np.array_equal(h5_matrix(path, n), tri_to_full(tri, n))
     hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
     assert "CHUNKED ( 256, 256 )" in hdr and "DEFLATE { LEVEL 6 }" in hdr and "H5T_STD_I32LE" in hdr
+    # 2 x 2 tiles of 512 with ragged edges, deflated in parallel and handed over with H5Dwrite_chunk (cli/sa_host.c:
+    # write_deflated_tiles), packed and full input; cross-check: libhdf5's own filter in one thread (SA_HOST_SERIAL_DEFLATE)
+    n = 700
+    tri = rng.integers(-500, 500, n * (n - 1) // 2, dtype=np.int32)
+    seqs700 = [bytes(rng.choice(list(b"ARNDCQEG"), 4).astype(np.uint8)) for _ in range(n)]
+    want = tri_to_full(tri, n)
+    for packed in (True, False):
+        path = tmp_path / f"par_{int(packed)}.h5"
+        host.write_hdf5(path, seqs700, amino_lut, tri if packed else want, packed, 6)
+        assert np.array_equal(h5_matrix(path, n), want)
+        assert h5_sequences(path) == seqs700
+        hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
+        assert "CHUNKED ( 512, 512 )" in hdr and "DEFLATE { LEVEL 6 }" in hdr
+    import os
+    os.environ["SA_HOST_SERIAL_DEFLATE"] = "1"
+    try:
+        path = tmp_path / "lib_filter.h5"
+        host.write_hdf5(path, seqs700, amino_lut, tri, True, 6)
+    finally:
+        del os.environ["SA_HOST_SERIAL_DEFLATE"]
+    assert np.array_equal(h5_matrix(path, n), want)
+    if H5DIFF.exists():
+        res = subprocess.run([str(H5DIFF), str(path), str(tmp_path / "par_1.h5")], capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
 
 
 @pytest.mark.skipif(not (ref_available() and H5DIFF.exists()), reason="needs oracle/_ref and h5diff")
-@pytest.mark.parametrize("n,z", [(100, 0), (300, 6)])
+@pytest.mark.parametrize("n,z", [(100, 0), (300, 6), (700, 9), (700, 1)])  # (N > 256 with -z: tiles deflated by all cores, H5Dwrite_chunk)
 def test_hdf5_equals_reference_writer(host, tmp_path, amino_lut, sa, oracle, n, z):
     from tests.synth import make_protein_set
     seqs = make_protein_set(n, 5, 20, 13)
