@@ -251,8 +251,10 @@ class TiledGatherStep:
             # ONE compute stream: the super-chunks' kernels run one after the other (on streams of their own they would all
             # start together and finish together -- nothing for the gather of the first one to hide behind)
             self.compute = torch.cuda.Stream()
-            # the placement follows the all-gather on the SAME stream: one cross-stream hop (~15 us each) fewer per super-chunk
-            self.comm = torch.cuda.Stream()
+            # the placement follows the all-gather on the SAME stream: one cross-stream hop (~15 us each) fewer per super-chunk;
+            # with ONE super-chunk nothing overlaps anything, so kernels, gather and placement all run on the compute stream:
+            # no cross-stream event between them at all (a hop costs 20-40 us of a 2 ms step)
+            self.comm = torch.cuda.Stream() if self.chunks > 1 else self.compute
             self.deliver = self.comm
             self._event = torch.cuda.Event
         else:
@@ -275,11 +277,14 @@ class TiledGatherStep:
             for r in ranks:  # (more than one only when the other ranks are emulated here)
                 # from the second super-chunk on, the gather and the placement of the one before run beside these kernels
                 be.align_share(lo, cnt, self.world, r, self.my_share(c, r), cs, leave_room=c > 0)
+            one_stream = self.comm is cs
             done = self._event()
-            done.record(cs)
-            gathered = done
+            if not one_stream:
+                done.record(cs)
+            gathered = None if one_stream else done
             if dist is not None and self.world > 1:
-                self.comm.wait_event(done)
+                if not one_stream:
+                    self.comm.wait_event(done)
                 with (torch.cuda.stream(self.comm) if cuda else _null()):
                     # (the process group moves bytes; int16 is not among its dtypes, uint8 is)
                     dist.all_gather_into_tensor(self.shares[c].view(torch.uint8), self.my_share(c).view(torch.uint8))
@@ -290,6 +295,7 @@ class TiledGatherStep:
         fin = self._event()
         fin.record(self.deliver)
         self.main.wait_event(fin)
-        last = self._event()
-        last.record(cs)  # (the host stores of the last kernels are complete when the kernels are)
-        self.main.wait_event(last)
+        if self.deliver is not cs:
+            last = self._event()
+            last.record(cs)  # (the host stores of the last kernels are complete when the kernels are)
+            self.main.wait_event(last)
