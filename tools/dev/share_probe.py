@@ -42,6 +42,11 @@ def all_shares():
 t = bench(all_shares, 5)
 print(f"all {world} shares back to back: {t*1e3:.3f} ms ({t/world*1e3:.3f} per share)")
 
+# the placement alone: the gathered shares of all ranks (stale data for the others: same traffic) -> packed order
+shares = torch.zeros(world * e, dtype=torch.int16, device="cuda")
+t = bench(lambda: ctx.place_shares(0, store.pairs, world, shares.data_ptr(), True, full.data_ptr(), s, True))
+print(f"placement of {world} shares alone: {t*1e3:.3f} ms ({(2 * world * e + 4 * store.pairs) / t / 1e12:.2f} TB/s of shares read + matrix written)")
+del shares
 # the whole step of one rank without the fabric: my kernels, place of all shares, host copy of my piece (solo rehearsal)
 from sequencealigner_amd.distributed import HipShares, TiledGatherStep
 for chunks in (1, 2, 3):

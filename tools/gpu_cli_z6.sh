@@ -14,7 +14,7 @@ for mode in parallel serial; do
   rm -f /tmp/out_$mode.h5
   if [ $mode = serial ]; then export SA_HOST_SERIAL_DEFLATE=1; else unset SA_HOST_SERIAL_DEFLATE; fi
   echo "== $mode"
-  /usr/bin/time -f "wall %e s, user %U s, max RSS %M KB" cli/seqalign -i /tmp/cfg5.fasta -o /tmp/out_$mode.h5 -a nw -m blosum62 -p 4 -f 0.9 -z 6 -B -F -Q 2>&1 | grep -v amdgpu.ids
+  time (cli/seqalign -i /tmp/cfg5.fasta -o /tmp/out_$mode.h5 -a nw -m blosum62 -p 4 -f 0.9 -z 6 -B -F -Q 2>&1 | grep -v amdgpu.ids)
   ls -la /tmp/out_$mode.h5
 done
 /opt/conda/bin/h5diff /tmp/out_parallel.h5 /tmp/out_serial.h5 && echo "h5diff: identical contents"
