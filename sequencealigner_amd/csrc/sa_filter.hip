@@ -5,7 +5,7 @@
  * (float division, >=; filter.c:47-54).  Whether a pair is "similar" does not depend on the order, only
  * the keep/drop decision does.  So the O(N^2 L) part -- the boolean relation R[i][j] -- is computed here
  * as a bit matrix, and the host resolves the greedy keep/drop sequentially over j with word-wide ANDs
- * (sa_hip_filter in sa_driver.hip): bit-identical to the reference run with one thread.
+ * (sa_hip_filter in sa_abi.hip): bit-identical to the reference run with one thread.
  *
  * Mapping: a workgroup takes a 64(j) x 64(i) tile of pairs, stages the 128 sequences in LDS in pieces of
  * PIECE positions, every wave handles 16 rows j, lane = i.  matches accumulate in a VGPR per (lane, row);

@@ -307,15 +307,31 @@ __global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__
 	const int lane = threadIdx.x & 63;
 	const int32_t wave = (int32_t)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int32_t)(gridDim.x * 4);
 	typedef int32_t i32x4 __attribute__((ext_vector_type(4), aligned(4)));
+	constexpr int WIN = 1024; /* elements of a wave's LDS window = rows of the largest own-block tile */
+	__shared__ __attribute__((aligned(16))) T s_win[4 * WIN];
 	for (int32_t k = wave; k < nsegs; k += nwaves) {
 		const SaPlaceSeg sg = segs[k];
 		const T *src = shares + sg.src;
 		int32_t *dst = packed + sg.dst;
 		if (sg.flags & 1) { /* map = posmap (row -> position), rows [pos0, pos0 + count) */
-			/* A run is one tile's rows (<= 1024): up to four groups of four rows per lane.  The loads of all groups are issued
-			 * before the first gather and all gathers before the first store -- two round trips to memory per run instead
-			 * of eight (the pass is latency-bound: 2.5 TB/s with the groups one after the other). */
-			for (int32_t q0 = 0; q0 < sg.count; q0 += 1024) {
+			/* A run is one tile's rows (<= 1024).  The run is copied into this wave's LDS window with coalesced 16-byte loads
+			 * (runs are padded to multiples of 8 elements: SA_SHARE_PAD), the positions of four groups of four rows per lane
+			 * are looked up while that copy is in flight, and the scores are then gathered from LDS: the texture path sees
+			 * only whole cache lines (2-byte gathers from global memory kept the pass at 2.2 TB/s). */
+			T *const win = s_win + (threadIdx.x >> 6) * WIN;
+			if (sg.count > WIN) { /* (no tile is that large today: plain gathers) */
+				for (int32_t q = lane; q < sg.count; q += 64)
+					if (sg.pos0 + q >= sg.ia && sg.pos0 + q < sg.ib)
+						dst[sg.pos0 + q] = (int32_t)src[sg.map[sg.pos0 + q] - sg.pos0];
+				continue;
+			}
+			{
+				constexpr int32_t q0 = 0;
+				const int32_t n = sg.count, npad = (n + 7) & ~7;
+				constexpr int PER = 16 / (int)sizeof(T); /* elements per 16-byte load */
+				typedef T tvec __attribute__((ext_vector_type(16 / sizeof(T)), aligned(16)));
+				for (int32_t e = PER * lane; e < npad; e += PER * 64)
+					*reinterpret_cast<tvec *>(win + e) = *reinterpret_cast<const tvec *>(src + q0 + e);
 				i32x4 pp[4], v[4];
 				bool whole[4];
 #pragma unroll
@@ -325,11 +341,13 @@ __global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__
 					if (whole[g])
 						pp[g] = *reinterpret_cast<const i32x4 *>(sg.map + sg.pos0 + q);
 				}
+				/* (a tile that is its own block: the positions of its rows are its own positions, pos0 + [0, count)) */
+				const int32_t off = sg.pos0 + q0;
 #pragma unroll
 				for (int g = 0; g < 4; g++)
 					if (whole[g])
-						v[g] = i32x4{ (int32_t)src[pp[g].x - sg.pos0], (int32_t)src[pp[g].y - sg.pos0], (int32_t)src[pp[g].z - sg.pos0],
-							      (int32_t)src[pp[g].w - sg.pos0] };
+						v[g] = i32x4{ (int32_t)win[pp[g].x - off], (int32_t)win[pp[g].y - off], (int32_t)win[pp[g].z - off],
+							      (int32_t)win[pp[g].w - off] };
 #pragma unroll
 				for (int g = 0; g < 4; g++) {
 					const int32_t q = q0 + 256 * g + 4 * lane, r = sg.pos0 + q;

@@ -56,7 +56,7 @@ struct SaSysArgs {
 	int32_t *long_scratch;   /* strip-mined launch: per wave 2 lines of long_stride/2 ints            */
 	int64_t long_stride;     /* ints per wave (>= 2 * longest row stream of a wave)                   */
 	int32_t pk_base;         /* packed kernels: the constant baseline BASE                                     */
-	/* packed kernels: arranged copies of the store (sa_driver.hip: arranged_store), largest block first; rows = 0: none */
+	/* packed kernels: arranged copies of the store (sa_plan.cpp: sa_arrange_rows), largest block first; rows = 0: none */
 	const SaArranged *lvp;   /* packed kernels: the SA_PK_SORT_LEVELS arranged copies offered to the class of the tile being run */
 	int32_t npart;           /* packed kernels: partial tiles, their column pairs listed behind tprefix         */
 	int32_t out_nt;          /* packed kernels: out is host memory, store non-temporally                        */

@@ -67,7 +67,7 @@ SA_HD constexpr int sa_pk_wpb(int g, int k) { return g == 16 && k >= SA_PK_K16_W
 #define SA_PK_F16_MAX 0x7bff /* largest value of the 8-lane packed kernels: the largest finite f16 bit pattern */
 #define SA_PK_ROWS_OWN_BLOCK 1024 /* tiles of at least this many rows are their own arranged block */
 #define SA_PK_SORT_LEVELS 4 /* block sizes SA_PK_SORT_ROWS >> level offered to a launch whose tiles are smaller */
-#define SA_PK_SORT_ROWS 2048 /* rows per arranged block of the row store when a tile is smaller (sa_driver.hip: arranged_store) */
+#define SA_PK_SORT_ROWS 2048 /* rows per arranged block of the row store when a tile is smaller (sa_plan.cpp: sa_arrange_rows) */
 #define SA_PK_KMAX 24
 #define SA_PK_K_LIST(X) \
 	X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) \
@@ -90,7 +90,7 @@ SA_HD constexpr int sa_pk_wpb(int g, int k) { return g == 16 && k >= SA_PK_K16_W
 enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 + SA_PK_KMAX + 1,
 	     SA_PK_CLASSES_END = SA_PK16_CLASS0 + SA_PK16_KMAX + 1,
 	     /* ... and every packed class once more, + SA_PK_SMALL: the columns of the class that a plan runs in its SMALL tiles (the
-	      * lowest columns of the range, put at the end of the launch so that it tapers off: sa_driver.hip plan_build) */
+	      * lowest columns of the range, put at the end of the launch so that it tapers off: sa_plan.cpp: sa_plan_host) */
 	     SA_PK_SMALL = SA_PK_CLASSES_END - SA_PK_CLASS0,
 	     SA_PLAN_NCLASSES = SA_PK_CLASSES_END + SA_PK_SMALL };
 
@@ -101,7 +101,7 @@ enum : int { SA_PK_CLASS0 = SA_SYS_NCLASSES + 1, SA_PK16_CLASS0 = SA_PK_CLASS0 +
  * profiles/r03a_*).  8-lane groups: KLO = 1, 9, 17; 16-lane groups: KLO = 13, 21, ... 61.  The registers of a bundle are
  * those of its largest K (K <= 16: <= 127 VGPRs for every method, four waves per SIMD as before). */
 #define SA_PK_BUNDLE 8
-struct SaArranged { /* one arranged copy of the row store (sa_driver.hip: arranged_store); rows = 0: none */
+struct SaArranged { /* one arranged copy of the row store (sa_plan.cpp: sa_arrange_rows); rows = 0: none */
 	const uint8_t *codes;
 	const int32_t *off;    /* num+1 offsets into codes by position */
 	const int32_t *rowmap; /* position -> row                      */

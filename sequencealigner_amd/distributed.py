@@ -239,6 +239,7 @@ class TiledGatherStep:
 
         self.torch, self.be, self.dist = torch, backend, dist
         self.world, self.rank, self.solo = world, rank, bool(solo)
+        self._chained = False  # (the first step has waited for the caller's stream)
         self.pairs = tri(n)
         self.ranges = column_chunks(n, chunks)
         self.chunks = len(self.ranges)
@@ -268,10 +269,16 @@ class TiledGatherStep:
     def __call__(self):
         torch, dist, be = self.torch, self.dist, self.be
         cuda = be.device == "cuda"
-        start = self._event()
-        start.record(self.main)
         cs = self.compute
-        cs.wait_event(start)  # ordered after the previous step
+        if not (self._chained and self.comm is cs):
+            # ordered after whatever the caller has on its stream (and, with several streams of our own, after the previous
+            # step).  One super-chunk runs on the compute stream alone: that stream is in order by itself, and bouncing every
+            # step through the caller's stream (its wait for the previous step's end, then this event) puts two cross-queue
+            # hand-overs -- 20-50 us each -- between consecutive steps; only the first step waits for the caller.
+            start = self._event()
+            start.record(self.main)
+            cs.wait_event(start)
+            self._chained = True
         for c, (lo, cnt) in enumerate(self.ranges):
             ranks = [self.rank] if (dist is not None or self.world == 1 or self.solo) else range(self.world)
             for r in ranks:  # (more than one only when the other ranks are emulated here)

@@ -1,4 +1,4 @@
-"""GPU (-m gpu): arranged row streams of the packed kernels (sa_driver.hip: arranged_store; sa_systolic_pk.inc) against
+"""GPU (-m gpu): arranged row streams of the packed kernels (sa_plan.cpp: sa_arrange_rows; sa_systolic_pk.inc) against
 the oracle, at sizes where they engage and on the cases their bookkeeping makes delicate: device-memory output (blocks
 of several sizes, scores scattered inside a block through rowmap), host output (one tile per block, scores leaving in
 row order through posmap), ranges that start inside a column (the first columns of the range cannot use blocks),

@@ -115,7 +115,7 @@ def test_packed_and_s32_kernel_families_agree(sa, monkeypatch):
 def test_frame_budget_follows_the_shortest_sequence(method, gaps, shortest, sa, oracle):
     """The number of frame shifts in flight -- and with it the value range, the choice between the f16 three-way-max
     and the u16 two-way-max form of the 16-lane kernels, and the largest packed class -- follows the store's shortest
-    sequence (sa_driver.hip: pk_live): columns of 193..650 residues against rows whose shortest has 200 / 16 / 7 / 1
+    sequence (sa_plan.h: sa_pk_live): columns of 193..650 residues against rows whose shortest has 200 / 16 / 7 / 1
     residues (1, 1, 2 and 8 shifts in flight with 16-lane groups), the short rows repeated so that terminators really
     come min_len + 1 positions apart."""
     seqs = [seq_of(n, 7000 + n) for n in range(200, 385, 3)] + [seq_of(n, 7000 + n) for n in range(390, 660, 13)]
