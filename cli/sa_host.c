@@ -508,64 +508,116 @@ size_t sa_host_hdf5_chunk_dim(size_t dim)
 }
 
 /* Compressed output (-z): the deflate filter of libhdf5 runs in the one thread that calls H5Dwrite -- for cfg 5 (89 994
- * sequences, 484 tiles of 4096 x 4096, level 6) that is minutes of one core while the alignment took two seconds.  The tiles
- * are independent: every core gathers one tile (zero beyond the matrix; the packed triangle is expanded on the way, diagonal
- * 0), deflates it with zlib exactly as the filter would (compress2 = the stream H5Z_filter_deflate reads) and hands the
- * finished bytes to H5Dwrite_chunk, one writer at a time.  Same dataset, same chunk shape, same filter pipeline as the
- * reference's file (src/io/format/hdf5.c:70-112); h5diff-equal by test. */
+ * sequences, 484 tiles of 4096 x 4096, level 6) that is minutes of one core while the alignment took two seconds.  Tiles are
+ * independent, and so are SEGMENTS of a tile: a zlib stream may be a chain of raw deflate pieces that each end on a full
+ * flush (byte-aligned, no back-references across the cut -- what pigz does), under one header and the Adler-32 of the whole.
+ * So every core deflates one 4 MB segment of one tile; a batch of tiles is gathered (zero beyond the matrix; the packed
+ * triangle is expanded on the way, diagonal 0), deflated, stitched and handed to H5Dwrite_chunk, one writer at a time.
+ * Same dataset, same chunk shape, same filter pipeline as the reference's file (src/io/format/hdf5.c:70-112); any HDF5
+ * reader inflates it; h5diff-equal by test. */
+enum { SA_DEFLATE_SEGMENT = 4 << 20 };
+
 static int write_deflated_tiles(hid_t mset, size_t chunk, size_t dim, const int32_t *matrix, bool triangular, unsigned level)
 {
-	const size_t nc = (dim + chunk - 1) / chunk, tile_bytes = chunk * chunk * sizeof(int32_t);
-	const uLong bound = compressBound((uLong)tile_bytes);
+	const size_t nc = (dim + chunk - 1) / chunk, ntiles = nc * nc, tile_bytes = chunk * chunk * sizeof(int32_t);
+	const size_t nseg = (tile_bytes + SA_DEFLATE_SEGMENT - 1) / SA_DEFLATE_SEGMENT;
+	const size_t seg_bound = compressBound(SA_DEFLATE_SEGMENT) + 16, out_bound = 2 + nseg * seg_bound + 4;
 	int threads = omp_get_max_threads();
-	const size_t avail = sa_host_available_memory(); /* a tile and its deflated image per thread: 130 MB at chunk 4096 */
-	while (threads > 1 && avail && (size_t)threads * (tile_bytes + bound) > avail / 4)
-		threads--;
-	if ((size_t)threads > nc * nc)
-		threads = (int)(nc * nc);
+	/* tiles per batch: enough segments for every thread, within a quarter of the available memory */
+	size_t batch = ((size_t)threads + nseg - 1) / nseg;
+	const size_t avail = sa_host_available_memory();
+	while (batch > 1 && avail && batch * (tile_bytes + out_bound) > avail / 4)
+		batch--;
+	if (batch > ntiles)
+		batch = ntiles;
+	uint8_t *tiles = malloc(batch * tile_bytes), *outs = malloc(batch * out_bound);
+	size_t *seg_len = malloc(sizeof(size_t) * batch * nseg);
+	uLong *seg_adler = malloc(sizeof(uLong) * batch * nseg);
 	int rc = 0;
-#pragma omp parallel num_threads(threads)
-	{
-		int32_t *tile = malloc(tile_bytes);
-		Bytef *z = malloc(bound);
-		if (!tile || !z) {
-#pragma omp critical(sa_h5_write)
-			rc = rc ? rc : 2;
-		}
-#pragma omp barrier
-#pragma omp for schedule(dynamic, 1)
-		for (size_t c = 0; c < nc * nc; c++) {
-			if (rc)
-				continue;
-			const size_t cy = c / nc, cx = c % nc, j0 = cx * chunk;
-			for (size_t r = 0; r < chunk; r++) {
-				const size_t i = cy * chunk + r;
-				int32_t *dst = tile + r * chunk;
-				const size_t w = i < dim ? (j0 + chunk <= dim ? chunk : dim - j0) : 0;
-				if (!triangular) {
-					if (w)
-						memcpy(dst, matrix + i * dim + j0, w * sizeof(int32_t));
-				} else {
-					for (size_t q = 0; q < w; q++) {
-						const size_t j = j0 + q;
-						dst[q] = j < i ? matrix[i * (i - 1) / 2 + j] : j == i ? 0 : matrix[j * (j - 1) / 2 + i];
-					}
+	if (!tiles || !outs || !seg_len || !seg_adler)
+		rc = 2;
+	for (size_t c0 = 0; c0 < ntiles && !rc; c0 += batch) {
+		const size_t nb = c0 + batch <= ntiles ? batch : ntiles - c0;
+		/* gather: one tile row per unit of work */
+#pragma omp parallel for schedule(static, 16)
+		for (size_t u = 0; u < nb * chunk; u++) {
+			const size_t c = c0 + u / chunk, r = u % chunk, cy = c / nc, cx = c % nc, j0 = cx * chunk;
+			const size_t i = cy * chunk + r;
+			int32_t *dst = (int32_t *)(tiles + (u / chunk) * tile_bytes) + r * chunk;
+			const size_t w = i < dim ? (j0 + chunk <= dim ? chunk : dim - j0) : 0;
+			if (!triangular) {
+				if (w)
+					memcpy(dst, matrix + i * dim + j0, w * sizeof(int32_t));
+			} else {
+				for (size_t q = 0; q < w; q++) {
+					const size_t j = j0 + q;
+					dst[q] = j < i ? matrix[i * (i - 1) / 2 + j] : j == i ? 0 : matrix[j * (j - 1) / 2 + i];
 				}
-				if (w < chunk)
-					memset(dst + w, 0, (chunk - w) * sizeof(int32_t));
 			}
-			uLongf zlen = bound;
-			const int zrc = compress2(z, &zlen, (const Bytef *)tile, (uLong)tile_bytes, (int)level);
-#pragma omp critical(sa_h5_write)
-			{
-				hsize_t at[2] = { cy * chunk, cx * chunk };
-				if (zrc != Z_OK || H5Dwrite_chunk(mset, H5P_DEFAULT, 0, at, (size_t)zlen, z) < 0)
-					rc = rc ? rc : 1;
-			}
+			if (w < chunk)
+				memset(dst + w, 0, (chunk - w) * sizeof(int32_t));
 		}
-		free(z);
-		free(tile);
+		/* deflate: one segment per unit of work, raw streams that end on a full flush (the last one finishes) */
+		int bad = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(| : bad)
+		for (size_t u = 0; u < nb * nseg; u++) {
+			const size_t t = u / nseg, sgm = u % nseg;
+			const size_t off = sgm * SA_DEFLATE_SEGMENT, len = off + SA_DEFLATE_SEGMENT <= tile_bytes ? SA_DEFLATE_SEGMENT : tile_bytes - off;
+			const uint8_t *src = tiles + t * tile_bytes + off;
+			uint8_t *dst = outs + t * out_bound + 2 + sgm * seg_bound;
+			z_stream zs;
+			memset(&zs, 0, sizeof(zs));
+			if (deflateInit2(&zs, (int)level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) {
+				bad |= 1;
+				continue;
+			}
+			zs.next_in = (Bytef *)src;
+			zs.avail_in = (uInt)len;
+			zs.next_out = dst;
+			zs.avail_out = (uInt)seg_bound;
+			const int want = sgm + 1 == nseg ? Z_FINISH : Z_FULL_FLUSH;
+			const int zrc = deflate(&zs, want);
+			if ((want == Z_FINISH ? zrc != Z_STREAM_END : zrc != Z_OK) || zs.avail_in)
+				bad |= 1;
+			seg_len[u] = (size_t)zs.total_out;
+			seg_adler[u] = adler32(adler32(0L, Z_NULL, 0), src, (uInt)len);
+			deflateEnd(&zs);
+		}
+		if (bad) {
+			rc = 1;
+			break;
+		}
+		/* stitch and write, one tile after the other */
+		for (size_t t = 0; t < nb && !rc; t++) {
+			uint8_t *o = outs + t * out_bound;
+			const unsigned flevel = level < 2 ? 0 : level < 6 ? 1 : level == 6 ? 2 : 3;
+			unsigned flg = flevel << 6;
+			flg += 31 - ((0x78u << 8 | flg) % 31);
+			o[0] = 0x78;
+			o[1] = (uint8_t)flg;
+			size_t at = 2;
+			uLong adler = adler32(0L, Z_NULL, 0);
+			for (size_t sgm = 0; sgm < nseg; sgm++) {
+				const size_t off = sgm * SA_DEFLATE_SEGMENT, len = off + SA_DEFLATE_SEGMENT <= tile_bytes ? SA_DEFLATE_SEGMENT : tile_bytes - off;
+				if (at != 2 + sgm * seg_bound)
+					memmove(o + at, o + 2 + sgm * seg_bound, seg_len[t * nseg + sgm]);
+				at += seg_len[t * nseg + sgm];
+				adler = sgm ? adler32_combine(adler, seg_adler[t * nseg + sgm], (z_off_t)len) : seg_adler[t * nseg + sgm];
+			}
+			o[at++] = (uint8_t)(adler >> 24);
+			o[at++] = (uint8_t)(adler >> 16);
+			o[at++] = (uint8_t)(adler >> 8);
+			o[at++] = (uint8_t)adler;
+			const size_t c = c0 + t;
+			hsize_t pos[2] = { (c / nc) * chunk, (c % nc) * chunk };
+			if (H5Dwrite_chunk(mset, H5P_DEFAULT, 0, pos, at, o) < 0)
+				rc = 1;
+		}
 	}
+	free(seg_adler);
+	free(seg_len);
+	free(outs);
+	free(tiles);
 	if (rc == 2)
 		return fail("Out of memory during HDF5 conversion");
 	return rc ? fail("Failed to write chunk to HDF5") : 0;

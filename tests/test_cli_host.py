@@ -131,6 +131,26 @@ def test_hdf5_roundtrip_full_and_triangular(host, tmp_path, amino_lut):
     if H5DIFF.exists():
         res = subprocess.run([str(H5DIFF), str(path), str(tmp_path / "par_1.h5")], capture_output=True, text=True)
         assert res.returncode == 0, res.stdout + res.stderr
+    # tiles of 2048 x 2048 (16 MB): four 4 MB segments per tile, deflated independently and stitched into one zlib stream
+    # (full-flush cuts, one header, combined Adler-32) -- libhdf5's own inflate must read it back
+    n = 2100
+    tri = rng.integers(-300, 80, n * (n - 1) // 2, dtype=np.int32)
+    seqs_n = [b"ARND"] * n
+    want = tri_to_full(tri, n)
+    path = tmp_path / "segments.h5"
+    host.write_hdf5(path, seqs_n, amino_lut, tri, True, 2)
+    assert np.array_equal(h5_matrix(path, n), want)
+    hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
+    assert "CHUNKED ( 2048, 2048 )" in hdr and "DEFLATE { LEVEL 2 }" in hdr
+    os.environ["SA_HOST_SERIAL_DEFLATE"] = "1"
+    try:
+        ref_path = tmp_path / "segments_lib.h5"
+        host.write_hdf5(ref_path, seqs_n, amino_lut, want, False, 2)
+    finally:
+        del os.environ["SA_HOST_SERIAL_DEFLATE"]
+    if H5DIFF.exists():
+        res = subprocess.run([str(H5DIFF), str(ref_path), str(path)], capture_output=True, text=True)
+        assert res.returncode == 0, res.stdout + res.stderr
 
 
 @pytest.mark.skipif(not (ref_available() and H5DIFF.exists()), reason="needs oracle/_ref and h5diff")
