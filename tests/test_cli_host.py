@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from tests.golden_util import GOLDEN_DIR, load_case, tri_to_full
-from tests.host_binding import H5DIFF, H5DUMP, Host, HostError, h5_matrix, h5_sequences
+from tests.host_binding import H5DIFF, H5DUMP, ROOT, Host, HostError, h5_matrix, h5_sequences
 from tests.oracle_binding import RefLib, ref_available
 
 
@@ -218,3 +218,23 @@ def test_matrix_allocator_file_backed_branch(host, tmp_path, monkeypatch):
         del arr
         lib.sa_host_matrix_free(m, n, True)
     assert list(tmp_path.iterdir()) == []  # nothing left behind
+
+
+@pytest.mark.skipif(not H5DIFF.exists(), reason="h5diff not available")
+def test_hdf5_writer_under_sanitizers(tmp_path):
+    """cli/sa_host.c linked into tests/host_c/writer_check.c with -fsanitize=address,undefined: the segment-parallel
+    deflate path (tiles of 256 KB .. 64 MB, ragged edges, several segments per tile) against libhdf5's own filter path"""
+    exe = tmp_path / "writer_check"
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-g", "-fopenmp", "-Wall", "-Wextra", "-I/opt/conda/include",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", str(exe),
+                           str(ROOT / "tests" / "host_c" / "writer_check.c"), str(ROOT / "cli" / "sa_host.c"),
+                           "-L/opt/conda/lib", "-lhdf5", "-lz", "-Wl,-rpath,/opt/conda/lib"])
+    import os
+    for n, z in ((300, 6), (700, 9), (2100, 2), (4200, 1)):
+        a, b = tmp_path / f"p_{n}.h5", tmp_path / f"s_{n}.h5"
+        res = subprocess.run([str(exe), str(n), str(z), str(a), str(b)], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        assert res.returncode == 0 and "runtime error" not in res.stderr and "AddressSanitizer" not in res.stderr, res.stderr[-3000:]
+        diff = subprocess.run([str(H5DIFF), str(a), str(b)], capture_output=True, text=True)
+        assert diff.returncode == 0, diff.stdout + diff.stderr
+        a.unlink(), b.unlink()
