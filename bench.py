@@ -460,6 +460,10 @@ def main():
     # the host matrix of the tiled step: ONE packed matrix for the node, a shared mapping under /dev/shm that every rank
     # attaches and page-locks (the reference's single mmap-ed result, io/output.c:55); every rank's kernels store the
     # scores that rank computed straight into it, so together the ranks fill it exactly once
+    cpu_flag = pathlib.Path(f"/dev/shm/sa_bench_cpu_done_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}")
+    if rank == 0:
+        cpu_flag.unlink(missing_ok=True)  # (left behind by a run that died between its CPU leg and its last barrier)
+    fence()
     host = None
     if "tiled" in partitions:
         shm = f"/dev/shm/sa_bench_matrix_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}.bin"
@@ -568,7 +572,7 @@ def main():
     # rank 0 alone times the reference's CPU path on a bounded sample of the workload (all host cores) and compares its
     # scores with the same prefix of the host matrix the ranks filled; the other ranks sleep on a flag file meanwhile
     base = parity = None
-    flag = pathlib.Path(f"/dev/shm/sa_bench_cpu_done_{os.environ.get('MASTER_PORT', '0')}_{os.getuid()}")
+    flag = cpu_flag
     if rank == 0:
         try:
             if not args.no_cpu_baseline:
