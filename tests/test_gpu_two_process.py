@@ -75,20 +75,28 @@ def test_two_ranks_share_one_gpu_and_one_host_matrix(tmp_path):
     assert "TWO_PROCESS_OK 2" in res.stdout
 
 
-def test_bench_two_rank_code_path_on_one_gpu():
-    """bench.py's own N > 1 code with world = 2 (SA_BENCH_ONE_GPU_REHEARSAL: both ranks on device 0, gloo instead of RCCL):
-    shared host matrix under /dev/shm, super-chunk trial, timed steps, per-rank verification -- the JSON line must report
-    the gathered matrix and the host matrix verified on every rank"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_code_path_on_one_gpu(world):
+    """bench.py's own N > 1 code with world = 2 and 4 (SA_BENCH_ONE_GPU_REHEARSAL: every rank on device 0, gloo instead of
+    RCCL): shared host matrix under /dev/shm, the untimed trial over partition x super-chunks, timed steps, per-rank
+    verification, rank 0's CPU leg while the others wait on the flag file -- the JSON line must report the gathered matrix
+    and the host matrix verified on every rank, a cpu_baseline and a parity block without mismatches"""
     import json
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, SA_BENCH_ONE_GPU_REHEARSAL="1", OMP_NUM_THREADS="8",
                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--nseq", "3000"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(ROOT / "bench.py"), "--gpus", str(world), "--steps", "3", "--warmup", "1", "--nseq", "3000",
+           "--cpu-seconds", "2"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["n_gpus"] == world and line["scaling"] == "strong" and line["value"] > 0
     assert line["config"]["gathered_and_host_result_verified_on_every_rank"] is True
+    trial = line["config"]["super_chunk_trial_ms"]
+    assert {"tiled x1", "tiled x2", "tiled x3", "range x1", "range x2"} <= set(trial)
+    assert line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["kind"] in ("reference", "port")
+    assert line["parity"]["mismatches"] == 0 and line["parity"]["pairs_compared"] > 10_000
+    assert line["dtype"] == "u16x2"
