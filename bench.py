@@ -325,10 +325,29 @@ def s32_kernels_leg(seqs, cfg, steps: int, torch, sa) -> dict:
         dest.close()
 
 
+_json_fd = None
+
+
+def emit(line: dict) -> None:
+    """the ONE JSON line of the run, on the process's original stdout"""
+    data = (json.dumps(line) + "\n").encode()
+    if _json_fd is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_json_fd, data)
+
+
 def main():
+    global _json_fd
     args = parse_args()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not os.environ.get("SA_BENCH_FORCE_DIST"):
         raise SystemExit(self_launch(args))
+    # stdout carries the JSON line and nothing else: whatever libraries print there (RCCL announces its version on stdout
+    # when a communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    _json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy as np
     import torch
@@ -443,7 +462,7 @@ def main():
             out["extra"] = {"configs": extra,
                             # the same cfg 2 step with the packed kernels switched off: the reference-width (s32) systolic kernels
                             "s32_kernels": s32_kernels_leg(seqs, cfg, 3, torch, sa)}
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     # ---- N > 1 (or the 1-rank RCCL rehearsal): tile-interleaved shares + overlapped all-gathers + per-rank host delivery ----
@@ -609,7 +628,7 @@ def main():
             "cpu_baseline": base,
             "parity": parity,
         }
-        print(json.dumps(out), flush=True)
+        emit(out)
     ctx.close()
     dist.barrier()
     if host is not None:

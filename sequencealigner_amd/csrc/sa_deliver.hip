@@ -54,6 +54,21 @@ bool sa_host_range_is_pinned(const void *p, size_t bytes)
 	return byte_is_pinned(hi - 1);
 }
 
+/* some of [p, p + bytes) is page-locked, but not the range as one registration (pieces, a hole, a registration that ends
+ * inside it): the runtime refuses a copy that crosses a registration boundary, and the range cannot be registered as a
+ * whole either -- such a destination is filled by the host from the library's own pinned staging buffers */
+static bool host_range_is_partly_pinned(const void *p, size_t bytes)
+{
+	if (!p || !bytes || sa_host_range_is_pinned(p, bytes))
+		return false;
+	const char *lo = static_cast<const char *>(p), *hi = lo + bytes;
+	constexpr size_t STEP = (size_t)2 << 20;
+	for (const char *q = lo; q < hi; q += STEP)
+		if (byte_is_pinned(q))
+			return true;
+	return byte_is_pinned(hi - 1);
+}
+
 namespace {
 
 constexpr int64_t BATCH_PAIRS = (int64_t)64 << 20; /* reference batch: src/interface/seqalign_cuda.c:136 */
@@ -228,11 +243,11 @@ bool deliver_full_shells(sa_ctx *ctx, int64_t j0, int64_t j1, int32_t *matrix, d
  * destination: straight into the caller's matrix; full destination (range not column-aligned, or the device
  * cannot hold N^2): staged in pinned memory and scattered by the host like output_fill. */
 bool deliver_batches(sa_ctx *ctx, int64_t lo, int64_t total, const sa_output &out, int64_t batch, bool shrink,
-		     double &phase_seconds)
+		     bool stage_packed, double &phase_seconds)
 {
 	auto &d = ctx->dl;
 	const size_t dim = (size_t)ctx->num;
-	const bool stage = out.matrix && !out.triangular;
+	const bool stage = out.matrix && (!out.triangular || stage_packed);
 	const auto t_phase = std::chrono::steady_clock::now();
 	int64_t issued = 0;
 	int nb = 0;
@@ -244,7 +259,9 @@ bool deliver_batches(sa_ctx *ctx, int64_t lo, int64_t total, const sa_output &ou
 	auto deliver_oldest = [&]() -> bool {
 		const Pending pd = pend[0];
 		SA_HIP_CHECK(hipEventSynchronize(d.copied[pd.buf]), return false);
-		if (stage)
+		if (stage && out.triangular)
+			memcpy(out.matrix + pd.start, d.h_stage[pd.buf], sizeof(int32_t) * (size_t)pd.count);
+		else if (stage)
 			host_scatter_full(out.matrix, dim, d.h_stage[pd.buf], pd.start, pd.count);
 		pend[0] = pend[1];
 		npend--;
@@ -263,7 +280,7 @@ bool deliver_batches(sa_ctx *ctx, int64_t lo, int64_t total, const sa_output &ou
 		SA_HIP_CHECK(hipEventRecord(d.done[b], d.compute), return false);
 		SA_HIP_CHECK(hipStreamWaitEvent(d.copy, d.done[b], 0), return false);
 		if (out.matrix) {
-			int32_t *dst = out.triangular ? out.matrix + lo + issued : d.h_stage[b];
+			int32_t *dst = stage ? d.h_stage[b] : out.matrix + lo + issued;
 			SA_HIP_CHECK(hipMemcpyAsync(dst, d.d_buf[b], sizeof(int32_t) * (size_t)cnt, hipMemcpyDeviceToHost, d.copy),
 				     return false);
 		}
@@ -351,8 +368,14 @@ static int align_host_impl(sa_ctx *ctx, int64_t start, int64_t count, struct sa_
 	/* Page-lock the destination so that the copies are true DMA and overlap the kernels (a pageable destination is
 	 * staged through a bounce buffer and serialises).  A caller that allocated the matrix with sa_hip_host_register /
 	 * hipHostMalloc has done this already.  Best effort: if registration fails the copies still work, only slower. */
+	/* (a destination that is page-locked only in part -- pieces, a hole: see host_range_is_partly_pinned -- is neither
+	 * registered here nor handed to the runtime as a copy target: the host fills it from pinned staging buffers) */
+	const bool partly = out.matrix && host_range_is_partly_pinned(out.triangular ? out.matrix + start : out.matrix,
+								      sizeof(int32_t) * (out.triangular ? (size_t)total : dim * dim));
+	if (partly)
+		shells = false;
 	void *pinned_here = nullptr;
-	if (out.matrix && !ctx->env.no_pin && (out.triangular || shells)) {
+	if (out.matrix && !partly && !ctx->env.no_pin && (out.triangular || shells)) {
 		int32_t *base = out.triangular ? out.matrix + start : out.matrix;
 		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)total : dim * dim);
 		const size_t avail = sa_host_available_bytes();
@@ -390,7 +413,7 @@ static int align_host_impl(sa_ctx *ctx, int64_t start, int64_t count, struct sa_
 		for (int k = 0; k < 2; k++)
 			if (!grow(d.d_buf[k], d.buf_elems[k], batch, false))
 				return 1;
-		if (out.matrix && !out.triangular)
+		if (out.matrix && (!out.triangular || partly))
 			for (int k = 0; k < 2; k++)
 				if (!grow(d.h_stage[k], d.stage_elems[k], batch, true))
 					return 1;
@@ -454,7 +477,7 @@ static int align_host_impl(sa_ctx *ctx, int64_t start, int64_t count, struct sa_
 		phase = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_phase).count();
 	} else {
 		ok = shells ? deliver_full_shells(ctx, j0, j1, out.matrix, phase)
-			    : deliver_batches(ctx, start, total, out, batch, out.matrix != nullptr, phase);
+			    : deliver_batches(ctx, start, total, out, batch, out.matrix != nullptr, partly && out.triangular, phase);
 	}
 	if (!ok) { /* leave nothing in flight that still targets the caller's memory */
 		(void)hipStreamSynchronize(d.compute);

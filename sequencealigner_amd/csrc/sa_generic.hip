@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void sa_k_place(const SaPlaceSeg *__restrict__
 	const int lane = threadIdx.x & 63;
 	const int32_t wave = (int32_t)((blockIdx.x * 256 + threadIdx.x) >> 6), nwaves = (int32_t)(gridDim.x * 4);
 	typedef int32_t i32x4 __attribute__((ext_vector_type(4), aligned(4)));
-	constexpr int WIN = 1024; /* elements of a wave's LDS window = rows of the largest own-block tile */
+	constexpr int WIN = 2048; /* elements of a wave's LDS window = rows of the largest own-block tile (eight waves x 8 streams x 32) */
 	__shared__ __attribute__((aligned(16))) T s_win[4 * WIN];
 	for (int32_t k = wave; k < nsegs; k += nwaves) {
 		const SaPlaceSeg sg = segs[k];

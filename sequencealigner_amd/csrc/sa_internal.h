@@ -89,7 +89,7 @@ hipError_t sa_launch_place(const SaPlaceSeg *segs, int32_t nsegs, const void *sh
 /* `workgroups` persistent workgroups pull the launch's wave-tiles from a.counter */
 hipError_t sa_launch_systolic(int method, int cls, const SaSysArgs &a, int workgroups, hipStream_t s);
 /* packed-u16 kernels: the bundle of classes a.pkc[0 .. a.npkc) (all of lane-group width g, K in [klo, klo + SA_PK_BUNDLE),
- * all three-way (f16) or not); lds_bytes = sa_pk_lds_bytes(g, largest K of the launch) */
+ * all three-way (f16) or not); lds_bytes = sa_pk_lds_bytes(method, g, largest K of the launch) */
 hipError_t sa_launch_systolic_pk(int method, int g, int klo, int f16, const SaSysArgs &a, int workgroups, unsigned lds_bytes,
 				 hipStream_t s);
 /* forces the code objects of the method's kernels onto the current device (module load outside any timed phase) */

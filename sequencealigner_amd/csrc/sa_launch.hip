@@ -437,7 +437,7 @@ static int align_range_launches(sa_ctx *ctx, int64_t start, int64_t count, int32
 		const int wgs = (int)std::min<int64_t>(is_pk ? pk_wgs : is_long ? ctx->long_wgs : ctx->persistent_wgs, ntiles_here);
 		if (is_pk) {
 			SA_HIP_CHECK(sa_launch_systolic_pk(ctx->sc.method, pb->g, pb->klo, pb->f16, a, wgs,
-							   (unsigned)sa_pk_lds_bytes(pb->g, pb->kmax), s), return 1);
+							   (unsigned)sa_pk_lds_bytes(ctx->sc.method, pb->g, pb->kmax), s), return 1);
 		} else {
 			SA_HIP_CHECK(sa_launch_systolic(ctx->sc.method, cls, a, wgs, s), return 1);
 		}

@@ -78,7 +78,7 @@ int sa_pk_arranged_keys(const SaPlanInputs &in, int pk_g, int pk_k, int32_t chun
 	if (in.no_sort || chunk_pk <= 0)
 		return 0;
 	const int ng = 64 / pk_g;
-	const int32_t rows = sa_pk_wpb(pk_g, pk_k) * ng * chunk_pk;
+	const int32_t rows = sa_pk_wpb(in.method, pk_g, pk_k) * ng * chunk_pk;
 	int nl = 0;
 	for (int l = 0; l < SA_PK_SORT_LEVELS; l++) {
 		const int32_t block = SA_PK_SORT_ROWS >> l;
@@ -268,7 +268,7 @@ bool sa_plan_host(const SaPlanInputs &in, int64_t start, int64_t count, int worl
 		if (rw.empty())
 			continue;
 		const SaPkCls pc = sa_pk_decode(cls);
-		const int64_t rows = (int64_t)sa_pk_wpb(pc.g, pc.k) * (64 / pc.g) * (pc.small ? plan.chunk_pk_small : plan.chunk_pk);
+		const int64_t rows = (int64_t)sa_pk_wpb(in.method, pc.g, pc.k) * (64 / pc.g) * (pc.small ? plan.chunk_pk_small : plan.chunk_pk);
 		tp[(size_t)cls].push_back(0);
 		std::vector<std::pair<int32_t, int32_t>> parts; /* (rows, pair) */
 		for (size_t c = 0; c < rw.size(); c += 2) {
@@ -347,7 +347,7 @@ bool sa_plan_host(const SaPlanInputs &in, int64_t start, int64_t count, int worl
 				SaArrKey lv[SA_PK_SORT_LEVELS];
 				sa_pk_arranged_keys(in, pk_g, K, cl.chunk, share_host, lv);
 				const int32_t lvrows[SA_PK_SORT_LEVELS] = { lv[0].block, lv[1].block, lv[2].block, lv[3].block };
-				const int32_t rows = sa_pk_wpb(pk_g, K) * (64 / pk_g) * cl.chunk;
+				const int32_t rows = sa_pk_wpb(in.method, pk_g, K) * (64 / pk_g) * cl.chunk;
 				const auto &rw = rows_of[(size_t)cls];
 				const int32_t npairs = (cl.ncols + 1) / 2, nfull = T[(size_t)npairs];
 				for (int32_t t = 0; t < cl.ntiles; t++) {
@@ -533,7 +533,7 @@ bool sa_plan_host(const SaPlanInputs &in, int64_t start, int64_t count, int worl
 				const auto &T = cl.tprefix;
 				const int32_t npairs = (cl.ncols + 1) / 2;
 				const bool small = sa_pk_decode(cl.cls).small;
-				const int64_t full_rows = (int64_t)sa_pk_wpb(b.g, sa_pk_decode(cl.cls).k) * (64 / b.g) * cl.chunk;
+				const int64_t full_rows = (int64_t)sa_pk_wpb(in.method, b.g, sa_pk_decode(cl.cls).k) * (64 / b.g) * cl.chunk;
 				int32_t pair_of_full = 0; /* (tiles ascend: the pair index only moves forward) */
 				for (int32_t t = 0; t < cl.ntiles; t++) {
 					uint32_t pair;

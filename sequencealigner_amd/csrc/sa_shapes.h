@@ -58,12 +58,18 @@ enum : int { SA_SYS_NCLASSES = (int)(sizeof(SA_SYS_CLASSES) / sizeof(SA_SYS_CLAS
 /* packed-u16 kernels (sa_systolic_pk.inc): 8-lane groups, K = 1..SA_PK_KMAX columns per lane (W = 8 K <= 192), two
  * column sequences per register, SA_PK_WPB waves per workgroup sharing the column pair's profile */
 #define SA_PK_WPB 4
-/* ... and EIGHT waves per workgroup where the profile is so large (16-lane groups, K >= 45: > 80 KB) that only one
- * workgroup fits a CU: eight waves sharing it put two waves on every SIMD instead of one (round 4; 600-1000 aa NW
- * 19.7 -> see DESIGN 4.2).  The split coincides with the translation units (sa_systolic_pk16hi_*.hip: K >= 45) and with
- * the bundle blocks (KLO = 45, 53, 61). */
+/* ... and EIGHT waves per workgroup (round 4)
+ *  - where the profile is so large (16-lane groups, K >= 45: > 80 KB) that only one workgroup fits a CU: eight waves
+ *    sharing it put two waves on every SIMD instead of one (600-1000 aa NW 19.7 -> 24.6 TCUPS).  The split
+ *    coincides with the translation units (sa_systolic_pk16hi_*.hip: K >= 45) and with the bundle blocks (KLO = 45, 53, 61);
+ *  - for NW with 8-lane groups and K = 17..24 (the bundle KLO = 17): 53 KB per four-wave workgroup are three workgroups
+ *    = three waves per SIMD, and NW wants four (three cost it 8 %); eight waves around one profile are 67 KB = two
+ *    workgroups = four waves per SIMD.  NW only: its 119 VGPRs allow four waves, Gotoh's 140 and SW's 149 do not. */
 #define SA_PK_K16_WIDE 45
-SA_HD constexpr int sa_pk_wpb(int g, int k) { return g == 16 && k >= SA_PK_K16_WIDE ? 2 * SA_PK_WPB : SA_PK_WPB; }
+SA_HD constexpr int sa_pk_wpb(int method, int g, int k)
+{
+	return (g == 16 && k >= SA_PK_K16_WIDE) || (method == SA_METHOD_NW && g == 8 && k >= 17) ? 2 * SA_PK_WPB : SA_PK_WPB;
+}
 #define SA_PK_F16_MAX 0x7bff /* largest value of the 8-lane packed kernels: the largest finite f16 bit pattern */
 #define SA_PK_ROWS_OWN_BLOCK 1024 /* tiles of at least this many rows are their own arranged block */
 #define SA_PK_SORT_LEVELS 4 /* block sizes SA_PK_SORT_ROWS >> level offered to a launch whose tiles are smaller */
@@ -124,7 +130,7 @@ struct SaPkClassArgs { /* one class of a bundle launch, in device memory */
 /* LDS of a packed workgroup: scores leaving the pipeline, token rings, then the profile of the column pair (the only
  * part that depends on K): a launch asks for the bytes of its largest K as dynamic LDS */
 SA_HD constexpr int sa_pk_lds_fixed(int g, int wpb) { return 416 * wpb * (64 / g); } /* per wave: 64/g groups x (32 scores x 2 halves x 2 B + a 144-entry u16 ring) */
-SA_HD constexpr int sa_pk_lds_bytes(int g, int k) { return sa_pk_lds_fixed(g, sa_pk_wpb(g, k)) + SA_CODE_ROWS * ((k + 3) / 4) * 256; }
+SA_HD constexpr int sa_pk_lds_bytes(int method, int g, int k) { return sa_pk_lds_fixed(g, sa_pk_wpb(method, g, k)) + SA_CODE_ROWS * ((k + 3) / 4) * 256; }
 inline int sa_pk_bundle_klo(int g, int k) { return g == 8 ? 1 + (k - 1) / SA_PK_BUNDLE * SA_PK_BUNDLE : SA_PK_K16_MIN + (k - SA_PK_K16_MIN) / SA_PK_BUNDLE * SA_PK_BUNDLE; }
 
 

@@ -21,6 +21,7 @@
 #include "../../sequencealigner_amd/csrc/sa_plan.h"
 
 static int g_fail = 0;
+static int g_method = 0; /* the scoring's method: the workgroup size of a packed class depends on it (sa_pk_wpb) */
 #define CHECK(cond, ...)                                        \
 	do {                                                    \
 		if (!(cond)) {                                  \
@@ -49,7 +50,7 @@ static TileGeo tile_geo(const SaHostPlan &pl, const SaHostClass &cl, int32_t t)
 	};
 	if (cl.cls >= SA_PK_CLASS0) {
 		const SaPkCls pc = sa_pk_decode(cl.cls);
-		const int32_t rows = sa_pk_wpb(pc.g, pc.k) * (64 / pc.g) * cl.chunk;
+		const int32_t rows = sa_pk_wpb(g_method, pc.g, pc.k) * (64 / pc.g) * cl.chunk;
 		const int32_t npairs = (cl.ncols + 1) / 2, nfull = cl.tprefix[(size_t)npairs];
 		int32_t lo;
 		if (t < nfull)
@@ -154,7 +155,7 @@ static void check_plan(const SaPlanInputs &in, const SaHostPlan &pl)
 	for (const auto &b : pl.bundles) {
 		CHECK(b.args.size() == b.cls.size() && (int)b.ufirst.size() == nranks + 1 && (int)b.nlocal.size() == nranks, "bundle shape");
 		CHECK(b.cls.size() <= ((size_t)1 << (32 - SA_PK_UTILE_BITS)), "bundle of %zu classes overflows the tile code", b.cls.size());
-		CHECK(sa_pk_lds_bytes(b.g, b.kmax) <= 160 * 1024, "bundle K %d: LDS", b.kmax);
+		CHECK(sa_pk_lds_bytes(g_method, b.g, b.kmax) <= 160 * 1024, "bundle K %d: LDS", b.kmax);
 		for (int r = 0; r < nranks; r++) {
 			CHECK(b.ufirst[(size_t)r + 1] - b.ufirst[(size_t)r] == 2 * (int64_t)b.nlocal[(size_t)r], "bundle: ufirst / nlocal disagree");
 			CHECK(b.ufirst[(size_t)r + 1] <= (int64_t)b.ulist.size(), "bundle: ulist too short");
@@ -325,6 +326,7 @@ int main(int argc, char **argv)
 		fprintf(stderr, "%s\n", sa_last_error());
 		return 2;
 	}
+	g_method = sc.method;
 	sc.gap_pen = -atoi(argv[4]);
 	sc.gap_opn = -atoi(argv[5]);
 	sc.gap_ext = -atoi(argv[6]);

@@ -155,3 +155,35 @@ def test_progress_polling_stays_out_of_the_timed_phase(sa):
     finally:
         dest.close()
         full.close()
+
+
+def test_destination_registered_in_pieces_with_a_hole_is_not_stored_into_directly(sa, oracle):
+    """a packed destination whose first and last bytes are page-locked but which is NOT one registration (two
+    registered pieces, an unregistered hole between them) must not take the direct-store path -- the kernels would fault
+    on the hole.  The range check asks the runtime for the registration that holds the first byte and requires it to reach
+    past the last one; the call falls back to staged copies and still delivers the reference's scores."""
+    import ctypes as C
+    from tests.synth import make_protein_set
+    store = sa.SequenceStore.from_sequences(make_protein_set(2500, 40, 120, 61))
+    scoring = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
+    lib = sa.load_library()
+    page = 4096
+    raw = np.zeros(store.pairs + 2 * page, np.int32)
+    start = (-raw.ctypes.data) % page // 4  # a page-aligned window inside the buffer
+    matrix = raw[start:start + store.pairs]
+    nbytes = matrix.nbytes
+    third = nbytes // 3 // page * page
+    head, tail = matrix.ctypes.data, matrix.ctypes.data + nbytes - third
+    assert lib.sa_hip_host_register(C.c_void_p(head), third) == 0
+    assert lib.sa_hip_host_register(C.c_void_p(tail), third) == 0
+    try:
+        with sa.Context(store, scoring, 0) as ctx:
+            ctx.align_host(matrix, triangular=True)
+        idx = np.sort(np.random.default_rng(5).integers(0, store.pairs, 30000))
+        assert np.array_equal(matrix[idx], oracle.align_pairs(store, scoring, idx, threads=16))
+        lo, hi = third // 4 - 1000, (nbytes - third) // 4 + 1000  # across both edges of the hole
+        assert np.array_equal(matrix[lo:lo + 2000], oracle.align_range(store, scoring, lo, 2000))
+        assert np.array_equal(matrix[hi - 2000:hi], oracle.align_range(store, scoring, hi - 2000, 2000))
+    finally:
+        lib.sa_hip_host_unregister(C.c_void_p(head))
+        lib.sa_hip_host_unregister(C.c_void_p(tail))
