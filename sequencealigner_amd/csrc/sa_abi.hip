@@ -145,14 +145,24 @@ static int32_t filter_impl(struct sa_input in, float threshold, uint8_t *keep)
 		SA_HIP_CHECK(hipMalloc(&d_rel, sizeof(unsigned long long) * band_words), break);
 		SA_HIP_CHECK(hipHostMalloc(&h_rel, sizeof(unsigned long long) * band_words), break);
 		std::vector<unsigned long long> keptbits((size_t)widest + 1, 0ULL);
+		const bool verbose = sa_env_read().verbose;
+		double ms_kernel = 0, ms_copy = 0, ms_host = 0;
 		keptbits[0] = 1ULL; /* sequence 0 is always kept */
 		bool failed = false;
 		for (int32_t jt0 = 0; jt0 < tiles && !failed; jt0 += band_tiles) {
 			const int32_t rows_t = std::min(band_tiles, tiles - jt0);
 			const long long j_lo = 64LL * jt0, j_hi = std::min<long long>(num, 64LL * (jt0 + rows_t));
 			const long long base = sa_filter_row_offset(j_lo), words = sa_filter_row_offset(j_hi) - base;
+			const auto t_band = std::chrono::steady_clock::now();
 			SA_HIP_CHECK(sa_launch_filter_relation(d_blob, d_off, num, threshold, d_rel, jt0, rows_t, nullptr), failed = true; break);
+			if (verbose) {
+				SA_HIP_CHECK(hipDeviceSynchronize(), failed = true; break);
+				ms_kernel += sa_ms_since(t_band);
+			}
+			const auto t_copy = std::chrono::steady_clock::now();
 			SA_HIP_CHECK(hipMemcpy(h_rel, d_rel, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost), failed = true; break);
+			ms_copy += sa_ms_since(t_copy);
+			const auto t_host = std::chrono::steady_clock::now();
 			/* greedy keep/drop in sequence order (filter.c:38-55 run with one thread) */
 			for (long long j = std::max<long long>(j_lo, 1); j < j_hi; j++) {
 				const unsigned long long *row = h_rel + (sa_filter_row_offset(j) - base);
@@ -165,7 +175,11 @@ static int32_t filter_impl(struct sa_input in, float threshold, uint8_t *keep)
 				else
 					keptbits[(size_t)(j / 64)] |= 1ULL << (j % 64);
 			}
+			ms_host += sa_ms_since(t_host);
 		}
+		if (verbose)
+			fprintf(stderr, "[seqalign_hip] sa_hip_filter: %d sequences: relation kernels %.1f ms, download %.1f ms, greedy pass on the host %.1f ms\n",
+				num, ms_kernel, ms_copy, ms_host);
 		if (failed)
 			break;
 		kept = 0;
