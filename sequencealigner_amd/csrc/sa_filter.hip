@@ -16,7 +16,8 @@
 namespace {
 
 constexpr int TILE = 64;
-constexpr int PIECE = 128;          /* positions staged per pass */
+constexpr int PIECE = 32;           /* positions staged per pass (a multiple of 4); after every pass the tile asks whether any of its
+                                     * pairs can still reach the threshold, see below */
 constexpr int ROWB = PIECE + 4;     /* LDS row stride: odd number of dwords -> conflict-free lane-per-row reads */
 
 /* 64-bit words of the relation before row j: sum_{j'<j} ceil(j'/64) */
@@ -88,6 +89,22 @@ __global__ __launch_bounds__(256) void sa_k_filter_relation(const uint8_t *__res
 				matches[r] += __builtin_popcount(~t);
 			}
 		}
+		/* Early exit (round 4).  A pair that has m matches after `done` positions ends with at most m + (ml - done): when not
+		 * even that reaches the threshold for ANY pair of the tile, the remaining passes cannot set a bit -- and unrelated
+		 * sequences are out after the first 32 positions (a twentieth of the positions match by chance; cfg 5 needs nine
+		 * tenths).  The bound is one match on the generous side of the final float test, so no similar pair is cut short. */
+		const int32_t done = p0 + PIECE;
+		int alive = 0;
+#pragma unroll
+		for (int r = 0; r < 16; r++) {
+			const int32_t j = j0 + wv * 16 + r;
+			const int32_t lj = j < num ? off[j + 1] - off[j] - 1 : 0;
+			const int32_t ml = len_i < lj ? len_i : lj;
+			const int32_t rem = ml > done ? ml - done : 0;
+			alive |= my_i < j && j < num && ml > 0 && (float)(matches[r] + rem + 1) / (float)ml >= threshold;
+		}
+		if (!__syncthreads_or(alive))
+			break;
 	}
 	/* fillers never match, so `matches` counts exactly the equal residues inside min(len_i, len_j) */
 #pragma unroll
