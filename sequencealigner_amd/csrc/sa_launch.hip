@@ -525,7 +525,8 @@ int sa_align_range_impl(sa_ctx *ctx, int64_t start, int64_t count, int32_t *d_sc
 	} else {
 		SA_HIP_CHECK(hipEventCreateWithFlags(&ctx->slot_done[slot], hipEventDisableTiming), return 1);
 	}
-	if (ctx->slot_dirty[slot]) {
+	if (ctx->slot_dirty[slot]) { /* (a launch of the failed call may still be running, on whatever stream: wait it out first) */
+		SA_HIP_CHECK(hipDeviceSynchronize(), return 1);
 		SA_HIP_CHECK(hipMemsetAsync(ctx->d_counters + slot * sa_ctx::COUNTERS_PER_SLOT, 0,
 					    sizeof(unsigned) * sa_ctx::COUNTERS_PER_SLOT, s), return 1);
 		ctx->slot_dirty[slot] = false;

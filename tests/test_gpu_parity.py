@@ -124,6 +124,39 @@ def test_device_filter_matches_reference_semantics(sa, oracle):
         assert sa.hip_filter(st, 0.0).all()
 
 
+def test_device_filter_late_matches_and_exact_thresholds(sa, oracle):
+    """the relation kernel leaves a tile once no pair can reach the threshold any more (matches so far + positions left):
+    pairs that disagree on a long prefix and agree on everything after it -- similar only through their LAST positions --
+    and pairs that sit exactly on / one residue below the threshold must come out as the reference's float test says"""
+    rng = np.random.default_rng(77)
+    letters = np.frombuffer(b"ARNDCQEGHILKMFPSTWYV", np.uint8)
+    def other(a):  # a residue different from a
+        return letters[(int(np.nonzero(letters == a)[0][0]) + 1 + int(rng.integers(0, 18))) % 20]
+    seqs = []
+    for length in (40, 64, 65, 100, 127, 128, 129, 200, 333):
+        base = letters[rng.integers(0, 20, length)]
+        seqs.append(base.tobytes())
+        for mism in (0, 1, length // 10 - 1, length // 10, length // 10 + 1, length // 4, length // 2):
+            if mism < 0 or mism > length:
+                continue
+            v = base.copy()  # mismatches packed into the FIRST positions: the pair looks hopeless for as long as possible
+            for q in range(mism):
+                v[q] = other(base[q])
+            seqs.append(v.tobytes())
+            w = base.copy()  # ... and into the last ones
+            for q in range(mism):
+                w[length - 1 - q] = other(base[length - 1 - q])
+            seqs.append(w.tobytes())
+            seqs.append(v.tobytes()[:length - 7])  # a shorter partner: min(len) decides
+    seqs += [letters[rng.integers(0, 20, int(n))].tobytes() for n in rng.integers(30, 300, 150)]  # unrelated company
+    order = rng.permutation(len(seqs))
+    st = sa.SequenceStore.from_sequences([seqs[k] for k in order])
+    for t in (0.9, 0.75, 0.5, 0.95, 0.1, 1.0):
+        got, want = sa.hip_filter(st, t), oracle.filter(st, t)
+        assert np.array_equal(got, want), (t, np.nonzero(got != want)[0][:10])
+        assert not want.all() or t == 1.0
+
+
 def test_error_behaviour(sa):
     sc = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
     with pytest.raises(sa.AlignError, match="Not enough sequences"):
