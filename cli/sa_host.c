@@ -623,11 +623,12 @@ static int write_deflated_tiles(hid_t mset, size_t chunk, size_t dim, const int3
 	return rc ? fail("Failed to write chunk to HDF5") : 0;
 }
 
-int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const int32_t *matrix, bool triangular,
-		       unsigned compression)
+/* the file, /sequences and the (empty) /similarity_matrix dataset: everything of flush_hdf5 (src/io/format/hdf5.c:14-112) up to
+ * the matrix data.  0 on success: *file_out, *mset_out open, *chunk_out = the chunk dimension (dim when contiguous). */
+static int open_output(const char *path, const struct sa_host_store *s, unsigned compression, hid_t *file_out, hid_t *mset_out,
+		       size_t *chunk_out)
 {
 	const size_t dim = (size_t)s->in.num;
-	int rc = 1;
 	hid_t fapl = H5Pcreate(H5P_FILE_ACCESS);
 	H5Pset_libver_bounds(fapl, H5F_LIBVER_LATEST, H5F_LIBVER_LATEST);
 	H5Pset_alignment(fapl, 4096, 4096);
@@ -678,6 +679,57 @@ int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const in
 		H5Fclose(file);
 		return fail("Failed to create HDF5 dataset for Similarity Matrix");
 	}
+	*file_out = file;
+	*mset_out = mset;
+	*chunk_out = chunk;
+	return 0;
+}
+
+/* Compressed output whose tiles arrive as finished zlib streams (the device-side encoder, sa_zjob_tile_row of
+ * include/seqalign_hip.h): same file, dataset, chunk shape and filter pipeline as sa_host_write_hdf5 with compression --
+ * the streams go to H5Dwrite_chunk as they are, tile row after tile row. */
+int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tile_row_fn next,
+			       void *user)
+{
+	const size_t dim = (size_t)s->in.num;
+	if (dim <= 256 || !compression)
+		return fail("Compressed tiles need a chunked dataset (more than 256 sequences) and a compression level");
+	hid_t file, mset;
+	size_t chunk;
+	if (open_output(path, s, compression, &file, &mset, &chunk))
+		return 1;
+	const size_t nc = (dim + chunk - 1) / chunk;
+	const uint8_t **streams = malloc(sizeof(*streams) * nc);
+	size_t *sizes = malloc(sizeof(*sizes) * nc);
+	int rc = streams && sizes ? 0 : fail("Out of memory during HDF5 conversion");
+	for (size_t r = 0; r < nc && !rc; r++) {
+		if (next(user, r, streams, sizes)) {
+			rc = fail("Failed to encode tile row %zu of the Similarity Matrix", r);
+			break;
+		}
+		for (size_t c = 0; c < nc && !rc; c++) {
+			hsize_t pos[2] = { r * chunk, c * chunk };
+			if (H5Dwrite_chunk(mset, H5P_DEFAULT, 0, pos, sizes[c], streams[c]) < 0)
+				rc = fail("Failed to write chunk to HDF5");
+		}
+	}
+	free(sizes);
+	free(streams);
+	H5Dclose(mset);
+	H5Fclose(file);
+	return rc;
+}
+
+int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const int32_t *matrix, bool triangular,
+		       unsigned compression)
+{
+	const size_t dim = (size_t)s->in.num;
+	int rc = 1;
+	herr_t st;
+	hid_t file, mset;
+	size_t chunk;
+	if (open_output(path, s, compression, &file, &mset, &chunk))
+		return 1;
 	if (dim > 256 && compression && !getenv("SA_HOST_SERIAL_DEFLATE")) {
 		rc = write_deflated_tiles(mset, chunk, dim, matrix, triangular, compression);
 	} else if (!triangular) {

@@ -396,7 +396,21 @@ int main(int argc, char **argv)
 	const size_t n = (size_t)store.in.num;
 	struct sa_output out = { NULL, NULL, n, false };
 	bool pinned = false;
-	if (!o.no_write) {
+	/* -z on a chunked dataset: the tiles are deflated on the device, from the packed scores where they were computed
+	 * (include/seqalign_hip.h: sa_hip_deflate_begin / sa_zjob_tile_row) -- no host matrix at all.  libhdf5's filter in the
+	 * one writing thread (what flush_hdf5 leaves to H5Dwrite, src/io/format/hdf5.c:148-194) takes 41 CPU-minutes for config 5.
+	 * SA_HOST_CPU_DEFLATE=1 keeps zlib at exactly the level asked for (all cores, sa_host_write_hdf5). */
+	const long long npairs = (long long)n * ((long long)n - 1) / 2;
+	const size_t zchunk = sa_host_hdf5_chunk_dim(n);
+	bool device_deflate = !o.no_write && o.compression > 0 && n > 256 && !getenv("SA_HOST_CPU_DEFLATE") &&
+			      !getenv("SA_HOST_SERIAL_DEFLATE");
+	if (device_deflate) {
+		/* the packed scores + one tile row of worst-case slots and streams (2 x 2.02 x the row's raw bytes) */
+		const size_t row_raw = ((n + zchunk - 1) / zchunk) * zchunk * zchunk * sizeof(int32_t);
+		device_deflate = sa_hip_memory(sizeof(int32_t) * (size_t)npairs + 5 * row_raw);
+		stamp("device memory probed (runtime up)");
+	}
+	if (!o.no_write && !device_deflate) {
 		const size_t full_bytes = sizeof(int32_t) * n * n;
 		const bool tmpf = sa_host_matrix_needs_file(n);
 		out.triangular = tmpf || !sa_hip_memory(full_bytes);
@@ -424,7 +438,7 @@ int main(int argc, char **argv)
 		stamp("matrix page-locked");
 	}
 
-	const long long pairs = (long long)n * ((long long)n - 1) / 2;
+	const long long pairs = npairs;
 	info("Performing %lld pairwise alignments", pairs);
 	/* progress (ppercent / pproportc in the reference's launch loop, src/interface/seqalign_cuda.c:181,286-289,293) */
 	const bool show_progress = !no_progress && !quiet;
@@ -433,31 +447,66 @@ int main(int argc, char **argv)
 		progress_line(0.0, NULL);
 	}
 	verb("Devices: %d (%s)", sa_hip_device_count(), sa_hip_device_name(0) ? sa_hip_device_name(0) : "none");
-	t0 = now();
-	if (!sa_hip_align(store.in, out, &sc)) {
-		err("%s", sa_last_error());
-		return 1;
-	}
-	t_align = now() - t0;
-	stamp("sa_hip_align returned");
-	if (show_progress) {
-		progress_line(1.0, NULL);
-		fputc('\n', stderr);
-		sa_hip_set_progress(NULL, NULL);
-	}
-	/* the reference times the launch/copy loop only (bench_align_start..end inside cuda_align,
-	 * src/interface/seqalign_cuda.c:182,292): device set-up and uploads are not part of "Alignment" */
-	const double t_setup = t_align - sa_hip_last_align_seconds();
-	t_align = sa_hip_last_align_seconds();
-
-	if (!o.no_write) {
+	double t_setup = 0;
+	int schedule = 0;
+	if (device_deflate) {
+		info("Similarity Matrix dimensions: %zu x %zu (deflated on the device, tile by tile)", n, n);
 		t0 = now();
-		if (sa_host_write_hdf5(o.output, &store, out.matrix, out.triangular, o.compression)) {
-			err("%s", sa_host_error());
+		double loop = 0;
+		sa_zjob *job = sa_hip_deflate_begin(store.in, &sc, zchunk, &loop);
+		if (!job) {
+			err("%s", sa_last_error());
 			return 1;
 		}
+		t_setup = now() - t0 - loop;
+		t_align = loop;
+		stamp("sa_hip_deflate_begin returned");
+		if (show_progress) {
+			progress_line(1.0, NULL);
+			fputc('\n', stderr);
+			sa_hip_set_progress(NULL, NULL);
+		}
+		t0 = now();
+		if (sa_host_write_hdf5_streams(o.output, &store, o.compression, (sa_host_tile_row_fn)sa_zjob_tile_row, job)) {
+			err("%s (%s)", sa_host_error(), sa_last_error());
+			return 1;
+		}
+		double enc_ms = 0, copy_ms = 0;
+		uint64_t raw = 0, outb = 0;
+		sa_zjob_stats(job, &enc_ms, &copy_ms, &raw, &outb);
+		verb("Deflated on the device: %.2f GB -> %.2f GB (%.2f : 1); the writer waited %.0f ms for the encoder, %.0f ms for gather + copy",
+		     (double)raw / 1e9, (double)outb / 1e9, outb ? (double)raw / (double)outb : 0.0, enc_ms, copy_ms);
+		sa_zjob_destroy(job);
 		t_out += now() - t0;
 		stamp("HDF5 written");
+	} else {
+		t0 = now();
+		if (!sa_hip_align(store.in, out, &sc)) {
+			err("%s", sa_last_error());
+			return 1;
+		}
+		t_align = now() - t0;
+		stamp("sa_hip_align returned");
+		if (show_progress) {
+			progress_line(1.0, NULL);
+			fputc('\n', stderr);
+			sa_hip_set_progress(NULL, NULL);
+		}
+		/* the reference times the launch/copy loop only (bench_align_start..end inside cuda_align,
+		 * src/interface/seqalign_cuda.c:182,292): device set-up and uploads are not part of "Alignment" */
+		t_setup = t_align - sa_hip_last_align_seconds();
+		t_align = sa_hip_last_align_seconds();
+		schedule = sa_hip_last_align_path();
+
+		if (!o.no_write) {
+			t0 = now();
+			if (sa_host_write_hdf5(o.output, &store, out.matrix, out.triangular, o.compression)) {
+				err("%s", sa_host_error());
+				return 1;
+			}
+			t_out += now() - t0;
+			stamp("HDF5 written");
+		}
 	}
 	if (o.benchmark) { /* -B: src/util/benchmark.c:50-64 */
 		const double total = t_in + t_filter + t_align + t_out;
@@ -465,9 +514,10 @@ int main(int argc, char **argv)
 		       "  Total: %.3f sec\n",
 		       t_in, t_filter, t_align, t_out, total);
 		printf("  (device set-up and upload, outside the phases as in the reference: %.3f sec)\n", t_setup);
-		printf("  (schedule: %s)\n", sa_hip_last_align_path() == 2
-						 ? "tiles dealt over the devices, RCCL all-gather of the dense shares, placement on every device"
-						 : "every device delivers its slice of the packed index straight into the host matrix");
+		printf("  (schedule: %s)\n", device_deflate ? "all pairs into device memory, tiles deflated on the device"
+				       : schedule == 2
+					       ? "tiles dealt over the devices, RCCL all-gather of the dense shares, placement on every device"
+					       : "every device delivers its slice of the packed index straight into the host matrix");
 		printf("Alignments per second: %.2f\n", t_align > 0 ? (double)pairs / t_align : 0.0);
 	}
 	if (pinned)

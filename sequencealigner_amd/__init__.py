@@ -20,6 +20,7 @@ Python/CPU fallback: a missing library or device raises.
 from .binding import (  # noqa: F401
     AlignError,
     Context,
+    DeflateJob,
     PinnedMatrix,
     Scoring,
     SequenceStore,

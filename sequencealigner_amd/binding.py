@@ -159,6 +159,16 @@ def load_library() -> C.CDLL:
     lib.sa_ctx_align_share.restype = C.c_int
     lib.sa_ctx_place_shares.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.sa_ctx_place_shares.restype = C.c_int
+    lib.sa_zjob_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t]
+    lib.sa_zjob_create.restype = C.c_void_p
+    lib.sa_zjob_destroy.argtypes = [C.c_void_p]
+    lib.sa_zjob_destroy.restype = None
+    lib.sa_zjob_tiles_per_row.argtypes = [C.c_void_p]
+    lib.sa_zjob_tiles_per_row.restype = C.c_size_t
+    lib.sa_zjob_tile_row.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.sa_zjob_tile_row.restype = C.c_int
+    lib.sa_zjob_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.sa_zjob_stats.restype = None
     _lib = lib
     return lib
 
@@ -531,3 +541,42 @@ class Context:
             raise AlignError(_err())
         return dict(kernel=name.value.decode(), launches=int(launches.value), ms=float(ms.value),
                     pairs=int(pairs.value), cells=int(cells.value), all_kernels_ms=float(all_ms.value))
+
+
+class DeflateJob:
+    """Device-side DEFLATE of a device-resident result matrix (sa_zjob_*, the -z option): the tiles (HDF5 chunks) of
+    the full symmetric matrix as zlib streams.  d_packed_ptr: scores by packed pair index; or d_full_ptr: N x N."""
+
+    def __init__(self, num: int, chunk_dim: int, d_packed_ptr: int = 0, d_full_ptr: int = 0, device: int = 0):
+        self._lib = load_library()
+        self._h = self._lib.sa_zjob_create(int(device), C.c_void_p(d_packed_ptr or None), C.c_void_p(d_full_ptr or None),
+                                           int(num), int(chunk_dim))
+        if not self._h:
+            raise AlignError(_err())
+        self.tiles_per_row = int(self._lib.sa_zjob_tiles_per_row(self._h))
+
+    def tile_row(self, row: int) -> list[bytes]:
+        """the zlib streams of tile row `row` (copied out of the job's page-locked buffer)"""
+        ptrs = (C.c_void_p * self.tiles_per_row)()
+        sizes = (C.c_size_t * self.tiles_per_row)()
+        if self._lib.sa_zjob_tile_row(self._h, int(row), ptrs, sizes):
+            raise AlignError(_err())
+        return [C.string_at(ptrs[t], sizes[t]) for t in range(self.tiles_per_row)]
+
+    def stats(self) -> dict:
+        e, c, r, o = C.c_double(), C.c_double(), C.c_uint64(), C.c_uint64()
+        self._lib.sa_zjob_stats(self._h, C.byref(e), C.byref(c), C.byref(r), C.byref(o))
+        return {"encode_ms": e.value, "copy_ms": c.value, "raw_bytes": r.value, "out_bytes": o.value}
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.sa_zjob_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -103,3 +103,34 @@ def test_cli_progress_line(tmp_path):
     for flag in ("-P", "-Q"):
         res = run("-i", fasta, "-W", "-a", "sw", "-m", "nuc44", "-s", 10, "-e", 1, "-F", flag)
         assert "Aligning sequences" not in res.stderr
+
+
+@pytest.mark.parametrize("n,method,flags", [
+    (700, "nw", ["-a", "nw", "-m", "blosum62", "-p", 4]),
+    (1300, "sw", ["-a", "sw", "-m", "blosum62", "-s", 10, "-e", 1]),
+])
+def test_cli_z_deflates_on_the_device(n, method, flags, tmp_path, sa):
+    """-z on a chunked dataset (N > 256): the tiles leave the GPU as zlib streams (csrc/sa_deflate.hip) and go to
+    H5Dwrite_chunk; the file reads back -- through libhdf5's own inflate -- as the same matrix the uncompressed path and the
+    all-cores zlib path (SA_HOST_CPU_DEFLATE=1) write, with the same dataset layout (h5diff, h5dump -p)."""
+    from tests.host_binding import H5DUMP
+    from tests.synth import make_protein_set
+    seqs = make_protein_set(n, 30, 150, 11)
+    fasta = tmp_path / "in.fasta"
+    write_fasta(fasta, seqs)
+    dev, cpu, plain = tmp_path / "dev.h5", tmp_path / "cpu.h5", tmp_path / "plain.h5"
+    res = run("-i", fasta, "-o", dev, *flags, "-z", 6, "-B", "-F", "-V")
+    assert "tiles deflated on the device" in res.stdout and "Deflated on the device" in res.stdout + res.stderr
+    run("-i", fasta, "-o", cpu, *flags, "-z", 6, "-F", "-Q", env={"SA_HOST_CPU_DEFLATE": "1"})
+    run("-i", fasta, "-o", plain, *flags, "-F", "-Q")
+    gaps = {"gap_pen": 4} if method == "nw" else {"gap_open": 10, "gap_extend": 1}
+    want = tri_to_full(sa.hip_align(sa.SequenceStore.from_sequences(seqs), sa.Scoring.from_names(method, "blosum62", **gaps),
+                                    triangular=True), n)
+    for path in (dev, cpu, plain):
+        assert np.array_equal(h5_matrix(path, n), want), path
+    assert h5_sequences(dev) == [s for s in seqs]
+    h5diff = H5DUMP.with_name("h5diff")
+    assert subprocess.run([str(h5diff), str(dev), str(cpu)], capture_output=True).returncode == 0
+    props = subprocess.run([str(H5DUMP), "-p", "-H", "-d", "/similarity_matrix", str(dev)], capture_output=True, text=True).stdout
+    assert "COMPRESSION DEFLATE { LEVEL 6 }" in props and "CHUNKED" in props
+    assert dev.stat().st_size < 0.6 * plain.stat().st_size

@@ -1,9 +1,10 @@
 #!/bin/bash
 # end to end through cli/seqalign with the options of BASELINE config 5 (-f 0.9 -z 6) on the first N sequences of the cfg 5 set:
-# FASTA -> device filter -> NW -> N x N HDF5 deflated at level 6; tiles deflated by all cores (default) vs libhdf5's filter in
-# the writing thread (SA_HOST_SERIAL_DEFLATE=1, what the reference's writer does).  usage: gpu_cli_z6.sh [N=30000]
+# FASTA -> device filter -> NW -> N x N HDF5 deflated: device = tiles deflated on the GPU (the default, csrc/sa_deflate.hip),
+# parallel = zlib level 6 on all cores (SA_HOST_CPU_DEFLATE=1), serial = libhdf5's filter in the writing thread
+# (SA_HOST_SERIAL_DEFLATE=1, what the reference's writer does).  usage: gpu_cli_z6.sh [N=30000] ["device parallel serial"]
 N=${1:-30000}
-MODES=${2:-parallel serial}   # (the full 100 000 sequences: parallel only -- the serial writer needs ~27 minutes)
+MODES=${2:-device parallel serial}   # (the full 100 000 sequences: not serial -- that writer needs ~27 minutes)
 df -h /tmp | tail -1
 python - $N <<'PY'
 import sys; sys.path.insert(0, ".")
@@ -14,11 +15,17 @@ PY
 nproc
 for mode in $MODES; do
   rm -f /tmp/out_$mode.h5
-  if [ $mode = serial ]; then export SA_HOST_SERIAL_DEFLATE=1; else unset SA_HOST_SERIAL_DEFLATE; fi
+  unset SA_HOST_SERIAL_DEFLATE SA_HOST_CPU_DEFLATE
+  [ $mode = serial ] && export SA_HOST_SERIAL_DEFLATE=1
+  [ $mode = parallel ] && export SA_HOST_CPU_DEFLATE=1
   echo "== $mode"
-  time (cli/seqalign -i /tmp/cfg5.fasta -o /tmp/out_$mode.h5 -a nw -m blosum62 -p 4 -f 0.9 -z 6 -B -F -Q 2>&1 | grep -v amdgpu.ids)
+  time (cli/seqalign -i /tmp/cfg5.fasta -o /tmp/out_$mode.h5 -a nw -m blosum62 -p 4 -f 0.9 -z 6 -B -F -V 2>&1 | grep -v '^Aligning' | grep -v amdgpu.ids)
   ls -la /tmp/out_$mode.h5
 done
-[ -f /tmp/out_serial.h5 ] && /opt/conda/bin/h5diff /tmp/out_parallel.h5 /tmp/out_serial.h5 && echo "h5diff: identical contents"
-/opt/conda/bin/h5dump -H -p /tmp/out_parallel.h5 | grep -E "DATASPACE|CHUNKED|DEFLATE|SIZE" | head -8
-rm -f /tmp/out_parallel.h5 /tmp/out_serial.h5 /tmp/cfg5.fasta
+first=""
+for mode in $MODES; do
+  [ -z "$first" ] && first=$mode && continue
+  /opt/conda/bin/h5diff /tmp/out_$first.h5 /tmp/out_$mode.h5 && echo "h5diff $first vs $mode: identical contents"
+done
+/opt/conda/bin/h5dump -H -p /tmp/out_$first.h5 | grep -E "DATASPACE|CHUNKED|DEFLATE|SIZE" | head -8
+rm -f /tmp/out_device.h5 /tmp/out_parallel.h5 /tmp/out_serial.h5 /tmp/cfg5.fasta
