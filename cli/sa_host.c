@@ -685,15 +685,15 @@ static int open_output(const char *path, const struct sa_host_store *s, unsigned
 	return 0;
 }
 
-/* Compressed output whose tiles arrive as finished zlib streams (the device-side encoder, sa_zjob_tile_row of
- * include/seqalign_hip.h): same file, dataset, chunk shape and filter pipeline as sa_host_write_hdf5 with compression --
- * the streams go to H5Dwrite_chunk as they are, tile row after tile row. */
+/* Output whose tiles arrive finished (sa_zjob_tile_row of include/seqalign_hip.h): zlib streams from the device-side encoder
+ * when `compression` > 0, the raw tiles when 0.  Same file, dataset, chunk shape and filter pipeline as sa_host_write_hdf5 --
+ * the tiles go to H5Dwrite_chunk as they are, tile row after tile row. */
 int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tile_row_fn next,
 			       void *user)
 {
 	const size_t dim = (size_t)s->in.num;
-	if (dim <= 256 || !compression)
-		return fail("Compressed tiles need a chunked dataset (more than 256 sequences) and a compression level");
+	if (dim <= 256)
+		return fail("Tiles need a chunked dataset (more than 256 sequences)");
 	hid_t file, mset;
 	size_t chunk;
 	if (open_output(path, s, compression, &file, &mset, &chunk))

@@ -65,9 +65,10 @@ bool sa_host_matrix_needs_file(size_t num);
 int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const int32_t *matrix, bool triangular,
 		       unsigned compression);
 size_t sa_host_hdf5_chunk_dim(size_t dim); /* exposed for tests */
-/* ... and the same file from tiles that arrive as finished zlib streams (the device-side encoder of the -z option,
- * include/seqalign_hip.h: sa_zjob_tile_row has exactly this signature): next(user, r, streams, sizes) fills the
- * ceil(N / chunk) streams of tile row r, valid until its next call; they go to H5Dwrite_chunk unchanged. */
+/* ... and the same file from tiles that arrive finished -- zlib streams from the device-side encoder of the -z option, or
+ * (compression 0) the raw tiles; include/seqalign_hip.h: sa_zjob_tile_row has exactly this signature:
+ * next(user, r, streams, sizes) fills the ceil(N / chunk) tiles of tile row r, valid until its next call; they go to
+ * H5Dwrite_chunk unchanged. */
 typedef int (*sa_host_tile_row_fn)(void *user, size_t tile_row, const uint8_t **streams, size_t *sizes);
 int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tile_row_fn next,
 			       void *user);

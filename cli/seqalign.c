@@ -402,12 +402,16 @@ int main(int argc, char **argv)
 	 * SA_HOST_CPU_DEFLATE=1 keeps zlib at exactly the level asked for (all cores, sa_host_write_hdf5). */
 	const long long npairs = (long long)n * ((long long)n - 1) / 2;
 	const size_t zchunk = sa_host_hdf5_chunk_dim(n);
-	bool device_deflate = !o.no_write && o.compression > 0 && n > 256 && !getenv("SA_HOST_CPU_DEFLATE") &&
-			      !getenv("SA_HOST_SERIAL_DEFLATE");
+	bool device_deflate = !o.no_write && n > 256 && !getenv("SA_HOST_MATRIX") &&
+			      (o.compression > 0 ? !getenv("SA_HOST_CPU_DEFLATE") && !getenv("SA_HOST_SERIAL_DEFLATE")
+						 /* without -z the same walk returns the tiles as they are: H5Dwrite_chunk instead of H5Dwrite's
+						  * gather of every tile out of N-wide rows.  One device only: on several, sa_hip_align's
+						  * all-devices alignment is worth more than the faster writer */
+						 : sa_hip_device_count() == 1);
 	if (device_deflate) {
-		/* the packed scores + one tile row of worst-case slots and streams (2 x 2.02 x the row's raw bytes) */
+		/* the packed scores + one tile row: raw, or worst-case slots and streams (2 x 2.02 x the row's raw bytes) */
 		const size_t row_raw = ((n + zchunk - 1) / zchunk) * zchunk * zchunk * sizeof(int32_t);
-		device_deflate = sa_hip_memory(sizeof(int32_t) * (size_t)npairs + 5 * row_raw);
+		device_deflate = sa_hip_memory(sizeof(int32_t) * (size_t)npairs + (o.compression ? 5 : 1) * row_raw);
 		stamp("device memory probed (runtime up)");
 	}
 	if (!o.no_write && !device_deflate) {
@@ -450,10 +454,10 @@ int main(int argc, char **argv)
 	double t_setup = 0;
 	int schedule = 0;
 	if (device_deflate) {
-		info("Similarity Matrix dimensions: %zu x %zu (deflated on the device, tile by tile)", n, n);
+		info("Similarity Matrix dimensions: %zu x %zu (%s on the device, tile by tile)", n, n, o.compression ? "deflated" : "tiled");
 		t0 = now();
 		double loop = 0;
-		sa_zjob *job = sa_hip_deflate_begin(store.in, &sc, zchunk, &loop);
+		sa_zjob *job = sa_hip_deflate_begin(store.in, &sc, zchunk, (int)o.compression, &loop);
 		if (!job) {
 			err("%s", sa_last_error());
 			return 1;
@@ -474,8 +478,9 @@ int main(int argc, char **argv)
 		double enc_ms = 0, copy_ms = 0;
 		uint64_t raw = 0, outb = 0;
 		sa_zjob_stats(job, &enc_ms, &copy_ms, &raw, &outb);
-		verb("Deflated on the device: %.2f GB -> %.2f GB (%.2f : 1); the writer waited %.0f ms for the encoder, %.0f ms for gather + copy",
-		     (double)raw / 1e9, (double)outb / 1e9, outb ? (double)raw / (double)outb : 0.0, enc_ms, copy_ms);
+		verb("%s on the device: %.2f GB -> %.2f GB (%.2f : 1); the writer waited %.0f ms for the encoder, %.0f ms for gather + copy",
+		     o.compression ? "Deflated" : "Tiled", (double)raw / 1e9, (double)outb / 1e9, outb ? (double)raw / (double)outb : 0.0, enc_ms,
+		     copy_ms);
 		sa_zjob_destroy(job);
 		t_out += now() - t0;
 		stamp("HDF5 written");
@@ -514,7 +519,8 @@ int main(int argc, char **argv)
 		       "  Total: %.3f sec\n",
 		       t_in, t_filter, t_align, t_out, total);
 		printf("  (device set-up and upload, outside the phases as in the reference: %.3f sec)\n", t_setup);
-		printf("  (schedule: %s)\n", device_deflate ? "all pairs into device memory, tiles deflated on the device"
+		printf("  (schedule: %s)\n", device_deflate ? (o.compression ? "all pairs into device memory, tiles deflated on the device"
+								       : "all pairs into device memory, tiles delivered as HDF5 chunks")
 				       : schedule == 2
 					       ? "tiles dealt over the devices, RCCL all-gather of the dense shares, placement on every device"
 					       : "every device delivers its slice of the packed index straight into the host matrix");

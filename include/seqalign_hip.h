@@ -200,19 +200,21 @@ int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t *d_full, vo
  * H5Dwrite hands the filter) over a DEVICE-resident matrix -- packed by pair index (d_packed) or full N x N (d_full,
  * used when d_packed is NULL) -- and returns every tile as a complete zlib stream (RFC 1950 / 1951) in page-locked host
  * memory, ready for H5Dwrite_chunk (filter mask 0); any inflate reads them.  The parse is fixed: the ratio
- * on score matrices sits between zlib -1 and -6, whatever level the dataset's property list names.
+ * on score matrices sits between zlib -1 and -6, whatever level > 0 the dataset's property list names.  Level 0 returns the
+ * tiles as they are (chunk_dim^2 int32 each), for a chunked dataset without filters: the same H5Dwrite_chunk loop then
+ * replaces H5Dwrite's gather of every tile out of N-wide rows in the writing thread (hdf5.c:148-194).
  *   sa_zjob_create       buffers for one tile row; chunk_dim: a power of two in [64, 4096] (sa_host_hdf5_chunk_dim)
  *   sa_zjob_tile_row     streams[t] / sizes[t] for the tiles_per_row tiles of row `tile_row`, valid until the next call;
  *                        rows are meant to be asked for in order: the next row is encoded while the caller writes
  *   sa_hip_deflate_begin sa_ctx_create + all pairs into device memory + sa_zjob_create on device 0; *align_seconds = the
  *                        launch loop alone (the bracket of sa_hip_last_align_seconds).  NULL + sa_last_error on failure. */
 typedef struct sa_zjob sa_zjob;
-sa_zjob *sa_zjob_create(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim);
+sa_zjob *sa_zjob_create(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim, int level);
 size_t sa_zjob_tiles_per_row(const sa_zjob *job);
 int sa_zjob_tile_row(sa_zjob *job, size_t tile_row, const uint8_t **streams, size_t *sizes);
 void sa_zjob_stats(const sa_zjob *job, double *encode_ms, double *copy_ms, uint64_t *raw_bytes, uint64_t *out_bytes);
 void sa_zjob_destroy(sa_zjob *job);
-sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, double *align_seconds);
+sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level, double *align_seconds);
 
 /* ---- pair-space planning (host only, no device needed) -------------------
  * DP cells (sum of len_i*len_j) of the packed pair range [start, start+count),

@@ -159,7 +159,7 @@ def load_library() -> C.CDLL:
     lib.sa_ctx_align_share.restype = C.c_int
     lib.sa_ctx_place_shares.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.sa_ctx_place_shares.restype = C.c_int
-    lib.sa_zjob_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t]
+    lib.sa_zjob_create.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_size_t, C.c_int]
     lib.sa_zjob_create.restype = C.c_void_p
     lib.sa_zjob_destroy.argtypes = [C.c_void_p]
     lib.sa_zjob_destroy.restype = None
@@ -545,12 +545,13 @@ class Context:
 
 class DeflateJob:
     """Device-side DEFLATE of a device-resident result matrix (sa_zjob_*, the -z option): the tiles (HDF5 chunks) of
-    the full symmetric matrix as zlib streams.  d_packed_ptr: scores by packed pair index; or d_full_ptr: N x N."""
+    the full symmetric matrix as zlib streams (level > 0) or as they are (level 0).  d_packed_ptr: scores by packed pair
+    index; or d_full_ptr: N x N."""
 
-    def __init__(self, num: int, chunk_dim: int, d_packed_ptr: int = 0, d_full_ptr: int = 0, device: int = 0):
+    def __init__(self, num: int, chunk_dim: int, d_packed_ptr: int = 0, d_full_ptr: int = 0, device: int = 0, level: int = 6):
         self._lib = load_library()
         self._h = self._lib.sa_zjob_create(int(device), C.c_void_p(d_packed_ptr or None), C.c_void_p(d_full_ptr or None),
-                                           int(num), int(chunk_dim))
+                                           int(num), int(chunk_dim), int(level))
         if not self._h:
             raise AlignError(_err())
         self.tiles_per_row = int(self._lib.sa_zjob_tiles_per_row(self._h))

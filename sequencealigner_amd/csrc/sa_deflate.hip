@@ -338,12 +338,24 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_gather(SaZArgs A, const uint3
 		dst[done + tid] = srcb[done + tid];
 }
 
+/* level 0: the tiles as they are (a chunked dataset without filters takes them through H5Dwrite_chunk just the same): one
+ * workgroup per row of a tile */
+__global__ __launch_bounds__(ZT) void sa_k_tiles_stored(SaZArgs A, uint32_t *out)
+{
+	const int r = blockIdx.x, tile = blockIdx.y;
+	const int64_t i = (int64_t)A.tile_row * A.chunk + r, j0 = (int64_t)(A.tile_col0 + tile) * A.chunk;
+	uint32_t *const o = out + ((size_t)tile * (size_t)A.chunk + (size_t)r) * (size_t)A.chunk;
+	for (int c = threadIdx.x; c < A.chunk; c += ZT)
+		o[c] = z_fetch(A, i, j0 + c);
+}
+
 } // namespace
 
 /* ---- host side ---------------------------------------------------------------------------------------------------- */
 struct sa_zjob {
 	int device = 0;
 	int32_t num = 0, chunk = 0, chunk_shift = 0, nc = 0, nseg = 0;
+	bool stored = false; /* level 0: raw tiles */
 	const int32_t *d_packed = nullptr, *d_full = nullptr;
 	int32_t *d_owned = nullptr; /* the packed matrix, when the job made it (sa_hip_deflate_begin) */
 	sa_ctx *ctx = nullptr;
@@ -407,6 +419,13 @@ static SaZArgs zjob_args(const sa_zjob *z, int64_t row)
 static bool zjob_encode(sa_zjob *z, int64_t row)
 {
 	const SaZArgs a = zjob_args(z, row);
+	if (z->stored) {
+		hipLaunchKernelGGL(sa_k_tiles_stored, dim3((unsigned)z->chunk, (unsigned)z->nc), dim3(ZT), 0, z->stream, a,
+				   reinterpret_cast<uint32_t *>(z->d_out));
+		SA_HIP_CHECK(hipGetLastError(), return false);
+		z->encoded_row = row;
+		return true;
+	}
 	hipLaunchKernelGGL(sa_k_deflate_segments, dim3((unsigned)z->nseg, (unsigned)z->nc), dim3(ZT), ZLDS_BYTES, z->stream, a);
 	SA_HIP_CHECK(hipGetLastError(), return false);
 	hipLaunchKernelGGL(sa_k_deflate_offsets, dim3((unsigned)z->nc), dim3(ZT), 0, z->stream, a, z->d_seg_off, z->d_out, z->tile_bound,
@@ -419,7 +438,7 @@ static bool zjob_encode(sa_zjob *z, int64_t row)
 	return true;
 }
 
-static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim)
+static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim, bool stored)
 {
 	if (num < 2 || (!d_packed && !d_full)) {
 		sa_set_error("sa_zjob: no matrix");
@@ -444,11 +463,20 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 	z->nseg = (int32_t)((chunk_dim * chunk_dim + ZSEG - 1) / ZSEG);
 	z->d_packed = d_packed;
 	z->d_full = d_packed ? nullptr : d_full;
+	z->stored = stored;
 	const size_t segs = (size_t)z->nc * (size_t)z->nseg;
 	/* a tile's stream at its very worst: header, 63 bits per element, the segments' ends */
 	z->tile_bound = (((size_t)z->nseg * ZSLOT_WORDS * 4 + 64) + 255) & ~(size_t)255;
+	if (stored)
+		z->tile_bound = chunk_dim * chunk_dim * sizeof(int32_t);
 	bool ok = false;
 	do {
+		SA_HIP_CHECK(hipStreamCreateWithFlags(&z->stream, hipStreamNonBlocking), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_out, (size_t)z->nc * z->tile_bound), break);
+		if (stored) {
+			ok = true;
+			break;
+		}
 		static std::atomic<unsigned long long> raised{ 0 }; /* bit d: more than 64 KB of dynamic LDS opted into on device d */
 		const unsigned long long bit = 1ull << (device & 63);
 		if (!(raised.load() & bit)) {
@@ -457,13 +485,11 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 				     break);
 			raised.fetch_or(bit);
 		}
-		SA_HIP_CHECK(hipStreamCreateWithFlags(&z->stream, hipStreamNonBlocking), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_slots, segs * ZSLOT_WORDS * sizeof(uint32_t)), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_seg_bytes, segs * sizeof(uint32_t)), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_s1, segs * sizeof(uint32_t)), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_s2, segs * sizeof(uint32_t)), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_seg_off, segs * sizeof(uint32_t)), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_out, (size_t)z->nc * z->tile_bound), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_tile_bytes, sizeof(unsigned long long) * (size_t)z->nc), break);
 		SA_HIP_CHECK(hipHostMalloc(&z->h_tile_bytes, sizeof(unsigned long long) * (size_t)z->nc, hipHostMallocDefault), break);
 		ok = true;
@@ -475,9 +501,9 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 	return z;
 }
 
-extern "C" sa_zjob *sa_zjob_create(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim)
+extern "C" sa_zjob *sa_zjob_create(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim, int level)
 {
-	return sa_guard("sa_zjob_create", (sa_zjob *)nullptr, [&] { return zjob_make(device, d_packed, d_full, num, chunk_dim); });
+	return sa_guard("sa_zjob_create", (sa_zjob *)nullptr, [&] { return zjob_make(device, d_packed, d_full, num, chunk_dim, level == 0); });
 }
 
 extern "C" void sa_zjob_destroy(sa_zjob *job)
@@ -503,7 +529,7 @@ extern "C" int sa_zjob_tile_row(sa_zjob *z, size_t tile_row, const uint8_t **str
 		const auto t1 = std::chrono::steady_clock::now();
 		size_t total = 0;
 		for (int t = 0; t < z->nc; t++) {
-			sizes[t] = (size_t)z->h_tile_bytes[t];
+			sizes[t] = z->stored ? z->tile_bound : (size_t)z->h_tile_bytes[t];
 			if (sizes[t] > z->tile_bound) {
 				sa_set_error("sa_zjob_tile_row: a tile's stream outgrew its bound (%zu > %zu)", sizes[t], z->tile_bound);
 				return 1;
@@ -519,10 +545,12 @@ extern "C" int sa_zjob_tile_row(sa_zjob *z, size_t tile_row, const uint8_t **str
 			SA_HIP_CHECK(hipHostMalloc(&z->h_buf, want, hipHostMallocDefault), return 1);
 			z->h_cap = want;
 		}
-		const SaZArgs a = zjob_args(z, (int64_t)tile_row);
-		hipLaunchKernelGGL(sa_k_deflate_gather, dim3((unsigned)z->nseg, (unsigned)z->nc), dim3(ZT), 0, z->stream, a, z->d_seg_off,
-				   z->d_out, z->tile_bound);
-		SA_HIP_CHECK(hipGetLastError(), return 1);
+		if (!z->stored) {
+			const SaZArgs a = zjob_args(z, (int64_t)tile_row);
+			hipLaunchKernelGGL(sa_k_deflate_gather, dim3((unsigned)z->nseg, (unsigned)z->nc), dim3(ZT), 0, z->stream, a, z->d_seg_off,
+					   z->d_out, z->tile_bound);
+			SA_HIP_CHECK(hipGetLastError(), return 1);
+		}
 		size_t at = 0;
 		for (int t = 0; t < z->nc; t++) {
 			SA_HIP_CHECK(hipMemcpyAsync(z->h_buf + at, z->d_out + (size_t)t * z->tile_bound, sizes[t], hipMemcpyDeviceToHost, z->stream),
@@ -557,7 +585,7 @@ extern "C" void sa_zjob_stats(const sa_zjob *z, double *encode_ms, double *copy_
 }
 
 /* the alignment into device memory (all pairs, packed) and a job over it; *align_seconds = the launch loop's time */
-extern "C" sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, double *align_seconds)
+extern "C" sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level, double *align_seconds)
 {
 	return sa_guard("sa_hip_deflate_begin", (sa_zjob *)nullptr, [&]() -> sa_zjob * {
 		sa_ctx *ctx = sa_ctx_create(0, in, sc);
@@ -578,7 +606,7 @@ extern "C" sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_sco
 			SA_HIP_CHECK(hipDeviceSynchronize(), break);
 			if (align_seconds)
 				*align_seconds = sa_ms_since(t0) * 1e-3;
-			z = zjob_make(0, d_packed, nullptr, in.num, chunk_dim);
+			z = zjob_make(0, d_packed, nullptr, in.num, chunk_dim, level == 0);
 			if (!z)
 				break;
 			ok = true;

@@ -134,3 +134,24 @@ def test_cli_z_deflates_on_the_device(n, method, flags, tmp_path, sa):
     props = subprocess.run([str(H5DUMP), "-p", "-H", "-d", "/similarity_matrix", str(dev)], capture_output=True, text=True).stdout
     assert "COMPRESSION DEFLATE { LEVEL 6 }" in props and "CHUNKED" in props
     assert dev.stat().st_size < 0.6 * plain.stat().st_size
+
+
+def test_cli_tiles_without_z_come_from_the_device(tmp_path, sa):
+    """N > 256 without -z on one device: the chunks are tiled on the device and written with H5Dwrite_chunk; the file is
+    the one the host-matrix path (SA_HOST_MATRIX=1: sa_hip_align + H5Dwrite) writes"""
+    from tests.host_binding import H5DUMP
+    from tests.synth import make_dna_set
+    n = 1100
+    seqs = make_dna_set(n, 60, 160, 9)
+    fasta = tmp_path / "in.fasta"
+    write_fasta(fasta, seqs)
+    dev, host = tmp_path / "dev.h5", tmp_path / "host.h5"
+    flags = ["-a", "sw", "-m", "nuc44", "-s", 10, "-e", 1]
+    res = run("-i", fasta, "-o", dev, *flags, "-B", "-F", "-Q")
+    if sa.device_count() == 1:
+        assert "tiles delivered as HDF5 chunks" in res.stdout
+    run("-i", fasta, "-o", host, *flags, "-F", "-Q", env={"SA_HOST_MATRIX": "1"})
+    want = tri_to_full(sa.hip_align(sa.SequenceStore.from_sequences(seqs), sa.Scoring.from_names("sw", "nuc44", gap_open=10, gap_extend=1),
+                                    triangular=True), n)
+    assert np.array_equal(h5_matrix(dev, n), want) and np.array_equal(h5_matrix(host, n), want)
+    assert subprocess.run([str(H5DUMP.with_name("h5diff")), str(dev), str(host)], capture_output=True).returncode == 0

@@ -111,3 +111,17 @@ def test_bad_arguments(sa):
     with sa.DeflateJob(5, 256, d_packed_ptr=d.data_ptr()) as job:
         with pytest.raises(sa.AlignError):
             job.tile_row(1)
+
+
+def test_level_zero_returns_the_tiles_as_they_are(sa):
+    """level 0 (a chunked dataset without filters): the same walk, tiles = chunk x chunk int32 LE, unencoded"""
+    import torch
+    n, chunk = 900, 256
+    rng = np.random.default_rng(3)
+    tri = rng.integers(-300, 300, size=n * (n - 1) // 2, dtype=np.int32)
+    full = tri_to_full(tri, n)
+    d = torch.from_numpy(tri).cuda()
+    nc, want = expected_tiles(full, chunk)
+    with sa.DeflateJob(n, chunk, d_packed_ptr=d.data_ptr(), level=0) as job:
+        for r in range(nc):
+            assert job.tile_row(r) == want[r]
