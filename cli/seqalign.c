@@ -409,9 +409,9 @@ int main(int argc, char **argv)
 						  * all-devices alignment is worth more than the faster writer */
 						 : sa_hip_device_count() == 1);
 	if (device_deflate) {
-		/* the packed scores + one tile row: raw, or worst-case slots and streams (2 x 2.02 x the row's raw bytes) */
+		/* the packed scores + one tile row: raw, or raw + worst-case slots and streams (1 + 2 x 2.02 x the row's raw bytes) */
 		const size_t row_raw = ((n + zchunk - 1) / zchunk) * zchunk * zchunk * sizeof(int32_t);
-		device_deflate = sa_hip_memory(sizeof(int32_t) * (size_t)npairs + (o.compression ? 5 : 1) * row_raw);
+		device_deflate = sa_hip_memory(sizeof(int32_t) * (size_t)npairs + (o.compression ? 6 : 1) * row_raw);
 		stamp("device memory probed (runtime up)");
 	}
 	if (!o.no_write && !device_deflate) {

@@ -4,22 +4,31 @@
  *
  * Reference: src/io/format/hdf5.c:91-95 sets H5Pset_deflate on the chunked dataset and H5Dwrite (:148-194) runs libhdf5's
  * deflate filter over every chunk in the one writing thread.  For BASELINE config 5 (89 994 sequences after `-f 0.9`,
- * 484 chunks of 4096 x 4096 int32 = 32.4 GB, level 6) that is 41 CPU-minutes behind a 2-second alignment
+ * 484 chunks of 4096 x 4096 int32 = 32.5 GB, level 6) that is 41 CPU-minutes behind a 2-second alignment
  * (profiles/r04_cli_cfg5_full_size_end_to_end.txt: Output 157 s with every core of the box deflating).  DEFLATE over int32
- * scores is HBM-bound byte work with a fixed parse (sa_deflate_core.h): it belongs where the scores are.
+ * scores with a fixed parse (sa_deflate_core.h) is byte work without a serial dependency between elements: it belongs
+ * where the scores are.
  *
- *   sa_k_deflate_segments   one workgroup per SEGMENT (64 KB of a tile: ZSEG elements in the tile's row-major order).
- *                           Elements come straight from the packed triangle (lower part: contiguous; upper part: the
- *                           mirrored element; diagonal and the padding beyond N: 0) into LDS; match choice + histograms
- *                           (LDS atomics) + Adler sums; 512-key bitonic sort; one thread builds the three Huffman codes
- *                           and writes the block header (sa_deflate_core.h: the code the host harness tests); then rounds
- *                           of 256 x ZE elements: bits per thread, workgroup scan, ds_or into an LDS bit stage, full
- *                           words flushed to the segment's slot.
- *   sa_k_deflate_offsets    one workgroup per tile: where each segment goes in the tile's stream, header, final block,
- *                           Adler-32 of the tile from the segments' sums.
- *   sa_k_deflate_gather     one workgroup per segment: its bytes to their place (dword copies with a funnel shift
- *                           between the byte alignment of slot and stream).
- * Host: a job walks the tile rows; row r + 1 is encoded while the host hands row r to H5Dwrite_chunk.
+ * A tile is cut into SEGMENTS of ZSEG elements (64 KB of its row-major bytes), each an independent dynamic-Huffman block
+ * that ends byte-aligned; ZGROUP consecutive segments (1 MB) share one set of Huffman codes.  Per tile row:
+ *   sa_k_deflate_hist     one workgroup per segment: its elements straight from the packed triangle (lower part:
+ *                         contiguous; upper part: the mirrored element; diagonal and the padding beyond N: 0) into LDS,
+ *                         match choice, histograms (LDS atomics, then one global atomic per used symbol into the
+ *                         group's histogram), Adler sums.
+ *   sa_k_deflate_codes    one workgroup per group: 512-key bitonic sort of the literal alphabet, then ONE thread builds the
+ *                         three length-limited codes and the block header (sa_deflate_core.h: the code the host harness
+ *                         tests) -- ~0.4 ms of dependent LDS round trips, which is why it runs once per megabyte and
+ *                         not in every segment's workgroup (first version: 460 us of a segment's 500 were this).
+ *   sa_k_deflate_encode   one workgroup per segment: elements into LDS again, the group's code tables and header, then
+ *                         rounds of 256 x ZE elements: bits per thread, workgroup scan, ds_or into an LDS bit stage, full
+ *                         words out to the segment's slot.
+ *   sa_k_deflate_offsets  one workgroup per tile: where each segment goes in the tile's stream, Adler-32 of the tile.
+ *   sa_k_deflate_rowbase  where each tile goes in the row's compact buffer.
+ *   sa_k_deflate_gather   one workgroup per segment: its bytes to their place (dword copies with a funnel shift
+ *                         between the byte alignment of slot and stream); the first one adds the tile's header and end.
+ * Host: a job walks the tile rows; row r + 1 is encoded AND copied to the host while the caller hands row r to
+ * H5Dwrite_chunk (the copy's length is not known when it is enqueued: it takes the previous row's length plus 3 %,
+ * and what that misses -- normally nothing -- follows when the sizes are there).
  */
 #include <algorithm>
 #include <chrono>
@@ -31,22 +40,36 @@
 namespace {
 
 constexpr int ZT = 256;     /* threads of a workgroup                                  */
-constexpr int ZE = 2;       /* elements per thread and round                           */
+constexpr int ZE = 4;       /* elements per thread and round of the encoder            */
 constexpr int ZSEG = 16384; /* elements per segment: 64 KB of the tile                 */
-/* the LDS bit stage holds the block header (<= 3 + 14 + 19 * 3 + 316 * 14 bits) and one round */
-constexpr int ZSTAGE_WORDS = (4600 + ZT * ZE * SA_Z_ELEM_BITS + 31) / 32 + 8;
+constexpr int ZGROUP = 16;  /* segments that share one set of codes: 1 MB of the tile  */
+constexpr int ZHDR_WORDS = (SA_Z_HEADER_BITS + 31) / 32 + 2;
+/* the LDS bit stage of the encoder holds the block header and one round */
+constexpr int ZSTAGE_WORDS = (SA_Z_HEADER_BITS + ZT * ZE * SA_Z_ELEM_BITS + 31) / 32 + 8;
 /* a segment's slot: header + 63 bits per element at the very worst, in words, a multiple of four */
 constexpr int ZSLOT_WORDS = 2 * ZSEG + 256;
-constexpr size_t ZLDS_BYTES = sizeof(uint32_t) * ZSEG + sizeof(SaZWork) + sizeof(uint32_t) * ZSTAGE_WORDS + 64;
+constexpr int ZHIST = 320; /* literal / length counters [0, 288), distance counters [288, 320) */
+
+struct SaZGroup { /* what sa_k_deflate_codes leaves for the segments of a group */
+	uint32_t lcode[288], dcode[32];
+	uint32_t hdr_bits, pad_[3];
+	uint32_t hdr[ZHDR_WORDS];
+};
 
 struct SaZArgs {
 	const int32_t *packed; /* scores by packed pair index j (j - 1) / 2 + i, i < j (src/io/output.c:76-83)     */
 	const int32_t *full;   /* ... or the full num x num matrix (packed == nullptr)                              */
 	int32_t num, chunk, chunk_shift;
 	int32_t tile_row, tile_col0;
-	int32_t nseg;          /* segments per tile                                                                 */
+	int32_t nseg, ngrp;    /* segments / code groups per tile                                                   */
 	uint32_t *slots;       /* [tile][segment][ZSLOT_WORDS]                                                      */
-	uint32_t *seg_bytes, *seg_s1, *seg_s2; /* [tile][segment]                                                  */
+	uint32_t *seg_bytes, *seg_s1, *seg_s2, *seg_off; /* [tile][segment]                                        */
+	uint32_t *ghist;       /* [tile][group][ZHIST]                                                              */
+	SaZGroup *groups;      /* [tile][group]                                                                     */
+	unsigned long long *tile_bytes, *tile_base; /* [tile], [tile + 1]: length of a tile's stream, its place in the row */
+	uint32_t *tile_adler;  /* [tile]                                                                            */
+	uint8_t *out;          /* the row's streams, compact (every tile starts on a 64-byte boundary)              */
+	uint32_t *raw;         /* [tile][chunk][chunk]: the row's tiles as they are (sa_k_tiles_raw)                 */
 };
 
 __device__ __forceinline__ uint32_t z_fetch(const SaZArgs &A, int64_t i, int64_t j)
@@ -59,6 +82,36 @@ __device__ __forceinline__ uint32_t z_fetch(const SaZArgs &A, int64_t i, int64_t
 		return 0u; /* the diagonal is never computed (src/io/output.c:76-81) and written as 0 */
 	const int64_t hi = i > j ? i : j, lo = i > j ? j : i;
 	return (uint32_t)A.packed[hi * (hi - 1) / 2 + lo];
+}
+
+/* Four consecutive elements of a segment and the eight before them, from the row's raw tiles: three 16-byte loads per
+ * lane, coalesced (the two older quads are the neighbouring lanes' own: cache hits).  e[8 + t] is element 4 q + t. */
+__device__ __forceinline__ void z_load_quad(const uint4 *seg4, uint32_t q, uint32_t (&e)[12])
+{
+	const uint4 z = { 0u, 0u, 0u, 0u };
+	const uint4 c = seg4[q], p1 = q >= 1 ? seg4[q - 1] : z, p2 = q >= 2 ? seg4[q - 2] : z;
+	e[0] = p2.x, e[1] = p2.y, e[2] = p2.z, e[3] = p2.w;
+	e[4] = p1.x, e[5] = p1.y, e[6] = p1.z, e[7] = p1.w;
+	e[8] = c.x, e[9] = c.y, e[10] = c.z, e[11] = c.w;
+}
+/* sa_z_match (sa_deflate_core.h) on registers: which of the eight elements before element k = 4 q + t has its bytes 1..3 */
+__device__ __forceinline__ int z_match_quad(const uint32_t (&e)[12], uint32_t k, int t)
+{
+	const uint32_t hi = e[8 + t] >> 8;
+	uint32_t m = 0;
+#pragma unroll
+	for (int j = 1; j <= SA_Z_J; j++)
+		m |= ((e[8 + t - j] >> 8) == hi ? 1u : 0u) << (j - 1);
+	if (k < (uint32_t)SA_Z_J) /* elements of the segment only */
+		m &= (1u << k) - 1u;
+	return m ? __ffs((int)m) : 0;
+}
+__device__ __forceinline__ const uint4 *z_segment(const SaZArgs &A, int seg, int tile, uint32_t *n)
+{
+	const uint32_t tile_elems = (uint32_t)A.chunk * (uint32_t)A.chunk;
+	const uint32_t e0 = (uint32_t)seg * ZSEG;
+	*n = tile_elems - e0 < (uint32_t)ZSEG ? tile_elems - e0 : (uint32_t)ZSEG; /* (a multiple of 4: tiles are at least 64 x 64) */
+	return reinterpret_cast<const uint4 *>(A.raw + (size_t)tile * tile_elems + e0);
 }
 
 __device__ __forceinline__ void z_or_bits(uint32_t *stage, uint32_t pos, uint64_t bits, uint32_t n)
@@ -78,54 +131,41 @@ __device__ __forceinline__ void z_or_bits(uint32_t *stage, uint32_t pos, uint64_
 		atomicOr(&stage[w + 2], x2);
 }
 
-__global__ __launch_bounds__(ZT) void sa_k_deflate_segments(SaZArgs A)
+__global__ __launch_bounds__(ZT) void sa_k_deflate_hist(SaZArgs A)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t z_lds[];
-	uint32_t *const el = reinterpret_cast<uint32_t *>(z_lds);
-	SaZWork &W = *reinterpret_cast<SaZWork *>(z_lds + sizeof(uint32_t) * ZSEG);
-	uint32_t *const stage = reinterpret_cast<uint32_t *>(z_lds + sizeof(uint32_t) * ZSEG + sizeof(SaZWork));
-	__shared__ uint32_t wave_sum[ZT / 64];
-
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	__shared__ uint32_t hist[ZHIST];
+	__shared__ unsigned long long s_s1, s_s2;
+	const int tid = threadIdx.x, lane = tid & 63;
 	const int seg = blockIdx.x, tile = blockIdx.y;
-	const int64_t i0 = (int64_t)A.tile_row * A.chunk, j0 = (int64_t)(A.tile_col0 + tile) * A.chunk;
-	const uint32_t tile_elems = (uint32_t)A.chunk * (uint32_t)A.chunk;
-	const uint32_t e0 = (uint32_t)seg * ZSEG;
-	const uint32_t n = tile_elems - e0 < (uint32_t)ZSEG ? tile_elems - e0 : (uint32_t)ZSEG;
-
-	/* ---- the segment's elements, histograms cleared ---- */
-	for (uint32_t k = tid; k < n; k += ZT) {
-		const uint32_t e = e0 + k;
-		el[k] = z_fetch(A, i0 + (e >> A.chunk_shift), j0 + (e & ((uint32_t)A.chunk - 1u)));
-	}
-	for (int s = tid; s < 288; s += ZT)
-		W.lfreq[s] = 0;
-	if (tid < 32)
-		W.dfreq[tid] = 0;
-	for (int s = tid; s < ZSTAGE_WORDS; s += ZT)
-		stage[s] = 0;
+	uint32_t n;
+	const uint4 *const seg4 = z_segment(A, seg, tile, &n);
+	for (int s = tid; s < ZHIST; s += ZT)
+		hist[s] = 0;
 	if (tid == 0)
-		W.s1 = W.s2 = 0ull;
+		s_s1 = s_s2 = 0ull;
 	__syncthreads();
 
-	/* ---- match choice, histograms, Adler sums ---- */
-	{
-		unsigned long long s1 = 0, s2 = 0;
-		const unsigned long long len = 4ull * n;
-		for (uint32_t k0 = 0; k0 < n; k0 += ZT) {
-			const uint32_t k = k0 + tid;
+	unsigned long long s1 = 0, s2 = 0;
+	const unsigned long long len = 4ull * n;
+	for (uint32_t q0 = 0; q0 < n / 4; q0 += ZT) {
+		const uint32_t q = q0 + tid;
+		const bool live = q < n / 4;
+		uint32_t e[12] = {};
+		if (live)
+			z_load_quad(seg4, q, e);
+#pragma unroll
+		for (int t = 0; t < 4; t++) {
+			const uint32_t k = 4u * q + (uint32_t)t, v = e[8 + t];
 			int j = -1;
-			uint32_t v = 0;
-			if (k < n) {
-				v = el[k];
-				j = sa_z_match(el, k);
-				atomicAdd(&W.lfreq[v & 255u], 1u);
+			if (live) {
+				j = z_match_quad(e, k, t);
+				atomicAdd(&hist[v & 255u], 1u);
 				if (!j) {
-					atomicAdd(&W.lfreq[(v >> 8) & 255u], 1u);
-					atomicAdd(&W.lfreq[(v >> 16) & 255u], 1u);
-					atomicAdd(&W.lfreq[v >> 24], 1u);
+					atomicAdd(&hist[(v >> 8) & 255u], 1u);
+					atomicAdd(&hist[(v >> 16) & 255u], 1u);
+					atomicAdd(&hist[v >> 24], 1u);
 				} else if (j > 1) {
-					atomicAdd(&W.dfreq[sa_z_dcode(j)], 1u);
+					atomicAdd(&hist[288 + sa_z_dcode(j)], 1u);
 				}
 				const uint32_t b0 = v & 255u, b1 = (v >> 8) & 255u, b2 = (v >> 16) & 255u, b3 = v >> 24;
 				const uint32_t sum = b0 + b1 + b2 + b3;
@@ -137,27 +177,53 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_segments(SaZArgs A)
 			const unsigned long long m_any = __ballot(j > 0), m_one = __ballot(j == 1);
 			if (lane == 0) {
 				if (m_any)
-					atomicAdd(&W.lfreq[SA_Z_LEN3], (uint32_t)__popcll(m_any));
+					atomicAdd(&hist[SA_Z_LEN3], (uint32_t)__popcll(m_any));
 				if (m_one)
-					atomicAdd(&W.dfreq[sa_z_dcode(1)], (uint32_t)__popcll(m_one));
+					atomicAdd(&hist[288 + sa_z_dcode(1)], (uint32_t)__popcll(m_one));
 			}
 		}
-		for (int d = 32; d > 0; d >>= 1) {
-			s1 += ((unsigned long long)(uint32_t)__shfl_down((int)(s1 >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)s1, d);
-			s2 += ((unsigned long long)(uint32_t)__shfl_down((int)(s2 >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)s2, d);
-		}
-		if (lane == 0) {
-			atomicAdd(&W.s1, s1);
-			atomicAdd(&W.s2, s2);
-		}
+	}
+	for (int d = 32; d > 0; d >>= 1) {
+		s1 += ((unsigned long long)(uint32_t)__shfl_down((int)(s1 >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)s1, d);
+		s2 += ((unsigned long long)(uint32_t)__shfl_down((int)(s2 >> 32), d) << 32) | (uint32_t)__shfl_down((int)(uint32_t)s2, d);
+	}
+	if (lane == 0) {
+		atomicAdd(&s_s1, s1);
+		atomicAdd(&s_s2, s2);
 	}
 	__syncthreads();
-	if (tid == 0)
-		W.lfreq[SA_Z_EOB] = 1;
+	uint32_t *const gh = A.ghist + ((size_t)tile * (size_t)A.ngrp + (size_t)(seg / ZGROUP)) * ZHIST;
+	for (int s = tid; s < ZHIST; s += ZT) {
+		const uint32_t c = hist[s] + (s == SA_Z_EOB ? 1u : 0u); /* every segment ends its block */
+		if (c)
+			atomicAdd(&gh[s], c);
+	}
+	if (tid == 0) {
+		const size_t at = (size_t)tile * (size_t)A.nseg + (size_t)seg;
+		A.seg_s1[at] = (uint32_t)(s_s1 % 65521ull);
+		A.seg_s2[at] = (uint32_t)(s_s2 % 65521ull);
+	}
+}
 
-	/* ---- literal alphabet by ascending weight: 512 keys (weight << 9 | symbol), bitonic, in the tree's storage ---- */
+__global__ __launch_bounds__(ZT) void sa_k_deflate_codes(SaZArgs A)
+{
+	__shared__ SaZWork W;
+	__shared__ uint32_t hdr[ZHDR_WORDS];
+	__shared__ uint32_t s_hdr_bits;
+	const int tid = threadIdx.x;
+	const size_t g = (size_t)blockIdx.y * (size_t)A.ngrp + (size_t)blockIdx.x;
+	const uint32_t *const gh = A.ghist + g * ZHIST;
+	for (int s = tid; s < 288; s += ZT)
+		W.lfreq[s] = gh[s];
+	if (tid < 32)
+		W.dfreq[tid] = gh[288 + tid];
+	for (int s = tid; s < ZHDR_WORDS; s += ZT)
+		hdr[s] = 0;
+	/* ---- literal alphabet by ascending weight: 512 keys (weight << 9 | symbol), bitonic, in the tree's storage.  A group
+	 * holds at most ZGROUP * (4 * ZSEG + 1) symbols: the weight fits 23 bits ---- */
 	uint32_t *const keys = W.w;
 	static_assert(sizeof(W.w) >= 512 * sizeof(uint32_t), "the sort keys fit the tree storage");
+	static_assert((uint64_t)ZGROUP * (4ull * ZSEG + 1ull) < (1ull << 23), "weight << 9 | symbol fits 32 bits");
 	__syncthreads();
 	for (int s = tid; s < 512; s += ZT)
 		keys[s] = s < SA_Z_NLIT && W.lfreq[s] ? (W.lfreq[s] << 9) | (uint32_t)s : 0xffffffffu;
@@ -187,32 +253,66 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_segments(SaZArgs A)
 		}
 	}
 	__syncthreads();
-
 	/* ---- one thread: code lengths, codes, block header (sa_deflate_core.h) ---- */
-	__shared__ uint32_t s_hdr_bits;
 	if (tid == 0) {
 		sa_z_alphabet(W, W.lfreq, SA_Z_NLIT, 15, W.llen, W.lcode, (int)W.used, true);
 		sa_z_alphabet(W, W.dfreq, SA_Z_NDIST, 15, W.dlen, W.dcode, 0, false);
-		SaZBits b{ stage, 0u };
+		SaZBits b{ hdr, 0u };
 		sa_z_header(W, b, false);
 		s_hdr_bits = b.pos;
 	}
 	__syncthreads();
+	SaZGroup &G = A.groups[g];
+	for (int s = tid; s < 288; s += ZT)
+		G.lcode[s] = s < SA_Z_NLIT ? W.lcode[s] : 0u;
+	if (tid < 32)
+		G.dcode[tid] = tid < SA_Z_NDIST ? W.dcode[tid] : 0u;
+	for (int s = tid; s < ZHDR_WORDS; s += ZT)
+		G.hdr[s] = hdr[s];
+	if (tid == 0)
+		G.hdr_bits = s_hdr_bits;
+}
+
+__global__ __launch_bounds__(ZT) void sa_k_deflate_encode(SaZArgs A)
+{
+	__shared__ uint32_t lcode[288], dcode[32], stage[ZSTAGE_WORDS];
+	__shared__ uint32_t wave_sum[ZT / 64];
+	__shared__ uint32_t s_tail_bytes;
+	static_assert(ZE == 4, "a thread encodes one quad per round");
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int seg = blockIdx.x, tile = blockIdx.y;
+	uint32_t n;
+	const uint4 *const seg4 = z_segment(A, seg, tile, &n);
+	const SaZGroup &G = A.groups[(size_t)tile * (size_t)A.ngrp + (size_t)(seg / ZGROUP)];
+	for (int s = tid; s < 288; s += ZT)
+		lcode[s] = G.lcode[s];
+	if (tid < 32)
+		dcode[tid] = G.dcode[tid];
+	for (int s = tid; s < ZSTAGE_WORDS; s += ZT)
+		stage[s] = s < ZHDR_WORDS ? G.hdr[s] : 0u;
+	uint32_t bitbase = __builtin_amdgcn_readfirstlane(G.hdr_bits), wbase = 0;
+	__syncthreads();
 
 	/* ---- rounds of ZT * ZE elements: bits, scan, ds_or into the stage, full words out ---- */
 	uint32_t *const out = A.slots + ((size_t)tile * (size_t)A.nseg + (size_t)seg) * ZSLOT_WORDS;
-	uint32_t bitbase = s_hdr_bits, wbase = 0;
 	for (uint32_t r0 = 0; r0 < n; r0 += ZT * ZE) {
 		uint64_t bits[ZE];
 		uint32_t nb[ZE], mine = 0;
+		{
+			const uint32_t q = r0 / 4 + (uint32_t)tid;
+			uint32_t el[12] = {};
+			const bool live = q < n / 4;
+			if (live)
+				z_load_quad(seg4, q, el);
 #pragma unroll
-		for (int e = 0; e < ZE; e++) {
-			const uint32_t k = r0 + (uint32_t)tid * ZE + (uint32_t)e;
-			nb[e] = 0;
-			bits[e] = 0;
-			if (k < n)
-				nb[e] = sa_z_element(W, el[k], sa_z_match(el, k), &bits[e]);
-			mine += nb[e];
+			for (int e = 0; e < ZE; e++) {
+				nb[e] = 0;
+				bits[e] = 0;
+				if (live)
+					nb[e] = sa_z_element(lcode, dcode, el[8 + e], z_match_quad(el, 4u * q + (uint32_t)e, e), &bits[e]);
+				mine += nb[e];
+			}
 		}
 		uint32_t incl = mine;
 		for (int d = 1; d < 64; d <<= 1) {
@@ -252,32 +352,25 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_segments(SaZArgs A)
 		bitbase = tot & 31u;
 	}
 	/* ---- end of block, empty stored block; the rest of the stage out ---- */
-	__shared__ uint32_t s_tail_bytes;
 	if (tid == 0) {
 		SaZBits b{ stage, bitbase };
-		s_tail_bytes = sa_z_finish_segment(W, b);
+		s_tail_bytes = sa_z_finish_segment(lcode, b);
 	}
 	__syncthreads();
 	const uint32_t tail_words = (s_tail_bytes + 3u) >> 2;
 	for (uint32_t w = tid; w < tail_words; w += ZT)
 		out[wbase + w] = stage[w];
-	if (tid == 0) {
-		const size_t at = (size_t)tile * (size_t)A.nseg + (size_t)seg;
-		A.seg_bytes[at] = wbase * 4u + s_tail_bytes;
-		A.seg_s1[at] = (uint32_t)(W.s1 % 65521ull);
-		A.seg_s2[at] = (uint32_t)(W.s2 % 65521ull);
-	}
+	if (tid == 0)
+		A.seg_bytes[(size_t)tile * (size_t)A.nseg + (size_t)seg] = wbase * 4u + s_tail_bytes;
 }
 
 /* where the segments of a tile go: [78 9c][segment 0]...[segment nseg-1][01 00 00 ff ff][Adler-32, big endian] */
-__global__ __launch_bounds__(ZT) void sa_k_deflate_offsets(SaZArgs A, uint32_t *seg_off, uint8_t *outb, size_t tile_bound,
-							   unsigned long long *tile_bytes)
+__global__ __launch_bounds__(ZT) void sa_k_deflate_offsets(SaZArgs A)
 {
 	__shared__ uint32_t s_len[1024], s_s1[1024], s_s2[1024];
 	const int tile = blockIdx.x, tid = threadIdx.x;
 	const size_t base = (size_t)tile * (size_t)A.nseg;
 	const uint32_t tile_elems = (uint32_t)A.chunk * (uint32_t)A.chunk;
-	uint8_t *const o = outb + (size_t)tile * tile_bound;
 	uint32_t at = 2, a = 1, b = 0; /* (a tile's stream stays far below 4 GB: <= 2 x 64 MB) */
 	for (int s0 = 0; s0 < A.nseg; s0 += 1024) {
 		const int cnt = A.nseg - s0 < 1024 ? A.nseg - s0 : 1024;
@@ -290,7 +383,7 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_offsets(SaZArgs A, uint32_t *
 		__syncthreads();
 		if (tid == 0) {
 			for (int s = 0; s < cnt; s++) {
-				seg_off[base + s0 + s] = at;
+				A.seg_off[base + s0 + s] = at;
 				at += s_len[s];
 				const uint32_t e0 = (uint32_t)(s0 + s) * ZSEG;
 				const uint32_t n = tile_elems - e0 < (uint32_t)ZSEG ? tile_elems - e0 : (uint32_t)ZSEG;
@@ -299,29 +392,47 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_offsets(SaZArgs A, uint32_t *
 		}
 	}
 	if (tid == 0) {
-		o[0] = 0x78;
-		o[1] = 0x9c;
-		o[at++] = 0x01;
-		o[at++] = 0x00;
-		o[at++] = 0x00;
-		o[at++] = 0xff;
-		o[at++] = 0xff;
-		o[at++] = (uint8_t)(b >> 8);
-		o[at++] = (uint8_t)b;
-		o[at++] = (uint8_t)(a >> 8);
-		o[at++] = (uint8_t)a;
-		tile_bytes[tile] = at;
+		A.tile_bytes[tile] = (unsigned long long)at + 9ull;
+		A.tile_adler[tile] = b << 16 | a;
 	}
 }
 
-__global__ __launch_bounds__(ZT) void sa_k_deflate_gather(SaZArgs A, const uint32_t *seg_off, uint8_t *outb, size_t tile_bound)
+__global__ void sa_k_deflate_rowbase(SaZArgs A, int ntiles)
+{
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		unsigned long long at = 0;
+		for (int t = 0; t < ntiles; t++) {
+			A.tile_base[t] = at;
+			at += (A.tile_bytes[t] + 63ull) & ~63ull;
+		}
+		A.tile_base[ntiles] = at;
+	}
+}
+
+__global__ __launch_bounds__(ZT) void sa_k_deflate_gather(SaZArgs A)
 {
 	const int seg = blockIdx.x, tile = blockIdx.y, tid = threadIdx.x;
 	const size_t at = (size_t)tile * (size_t)A.nseg + (size_t)seg;
 	const uint32_t *const srcw = A.slots + at * ZSLOT_WORDS;
 	const uint8_t *const srcb = reinterpret_cast<const uint8_t *>(srcw);
 	const uint32_t len = A.seg_bytes[at];
-	uint8_t *const dst = outb + (size_t)tile * tile_bound + seg_off[at];
+	uint8_t *const o = A.out + A.tile_base[tile];
+	if (seg == 0 && tid == 0) {
+		unsigned long long e = A.tile_bytes[tile] - 9ull;
+		const uint32_t adler = A.tile_adler[tile];
+		o[0] = 0x78;
+		o[1] = 0x9c;
+		o[e++] = 0x01;
+		o[e++] = 0x00;
+		o[e++] = 0x00;
+		o[e++] = 0xff;
+		o[e++] = 0xff;
+		o[e++] = (uint8_t)(adler >> 24);
+		o[e++] = (uint8_t)(adler >> 16);
+		o[e++] = (uint8_t)(adler >> 8);
+		o[e++] = (uint8_t)adler;
+	}
+	uint8_t *const dst = o + A.seg_off[at];
 	uint32_t head = (uint32_t)((4u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 3u)) & 3u);
 	if (head > len)
 		head = len;
@@ -329,24 +440,39 @@ __global__ __launch_bounds__(ZT) void sa_k_deflate_gather(SaZArgs A, const uint3
 		dst[tid] = srcb[tid];
 	const uint32_t nd = (len - head) >> 2, sh = 8u * (head & 3u);
 	uint32_t *const dstw = reinterpret_cast<uint32_t *>(dst + head);
-	for (uint32_t q = tid; q < nd; q += ZT) {
-		const uint32_t w0 = (head >> 2) + q; /* source byte head + 4 q */
-		dstw[q] = sh ? (srcw[w0] >> sh) | (srcw[w0 + 1] << (32u - sh)) : srcw[w0];
-	}
+	for (uint32_t q = tid; q < nd; q += ZT) /* source byte head + 4 q: word q, shifted */
+		dstw[q] = sh ? (srcw[q] >> sh) | (srcw[q + 1] << (32u - sh)) : srcw[q];
 	const uint32_t done = head + 4u * nd;
 	if ((uint32_t)tid < len - done)
 		dst[done + tid] = srcb[done + tid];
 }
 
-/* level 0: the tiles as they are (a chunked dataset without filters takes them through H5Dwrite_chunk just the same): one
- * workgroup per row of a tile */
-__global__ __launch_bounds__(ZT) void sa_k_tiles_stored(SaZArgs A, uint32_t *out)
+/* The tiles of a row as they are -- full symmetric matrix, zero diagonal, zeros beyond N -- from the packed triangle, in
+ * blocks of 64 x 64: one workgroup per block.  Below the diagonal a matrix row IS a run of the packed index (coalesced
+ * along j); above it the mirrored element sits in column j's run, contiguous along i: the block is read along i and
+ * turned in LDS, so both halves move whole cache lines (reading the upper half element by element along j fetched a
+ * line for every four bytes: the encoder's two passes spent half their time there).  Level 0 returns these tiles; the
+ * encoder reads them twice. */
+__global__ __launch_bounds__(ZT) void sa_k_tiles_raw(SaZArgs A)
 {
-	const int r = blockIdx.x, tile = blockIdx.y;
-	const int64_t i = (int64_t)A.tile_row * A.chunk + r, j0 = (int64_t)(A.tile_col0 + tile) * A.chunk;
-	uint32_t *const o = out + ((size_t)tile * (size_t)A.chunk + (size_t)r) * (size_t)A.chunk;
-	for (int c = threadIdx.x; c < A.chunk; c += ZT)
-		o[c] = z_fetch(A, i, j0 + c);
+	__shared__ uint32_t turn[64][65];
+	const int tile = blockIdx.z, tid = threadIdx.x;
+	const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+	const int64_t i0 = (int64_t)A.tile_row * A.chunk + r0, j0 = (int64_t)(A.tile_col0 + tile) * A.chunk + c0;
+	uint32_t *const o = A.raw + (size_t)tile * (size_t)A.chunk * (size_t)A.chunk + (size_t)r0 * (size_t)A.chunk + (size_t)c0;
+	const int x = tid & 63, y4 = tid >> 6;
+	if (A.packed && j0 >= i0 + 64) { /* strictly above the diagonal: element (i, j) = packed[tri(j) + i] */
+		for (int s = 0; s < 64; s += 4) {
+			const int64_t j = j0 + s + y4, i = i0 + x;
+			turn[s + y4][x] = i < A.num && j < A.num ? (uint32_t)A.packed[j * (j - 1) / 2 + i] : 0u;
+		}
+		__syncthreads();
+		for (int s = 0; s < 64; s += 4)
+			o[(size_t)(s + y4) * (size_t)A.chunk + x] = turn[x][s + y4];
+		return;
+	}
+	for (int s = 0; s < 64; s += 4) /* on or below the diagonal, or a full matrix: along j */
+		o[(size_t)(s + y4) * (size_t)A.chunk + x] = z_fetch(A, i0 + s + y4, j0 + x);
 }
 
 } // namespace
@@ -354,21 +480,28 @@ __global__ __launch_bounds__(ZT) void sa_k_tiles_stored(SaZArgs A, uint32_t *out
 /* ---- host side ---------------------------------------------------------------------------------------------------- */
 struct sa_zjob {
 	int device = 0;
-	int32_t num = 0, chunk = 0, chunk_shift = 0, nc = 0, nseg = 0;
+	int32_t num = 0, chunk = 0, chunk_shift = 0, nc = 0, nseg = 0, ngrp = 0;
 	bool stored = false; /* level 0: raw tiles */
 	const int32_t *d_packed = nullptr, *d_full = nullptr;
 	int32_t *d_owned = nullptr; /* the packed matrix, when the job made it (sa_hip_deflate_begin) */
 	sa_ctx *ctx = nullptr;
-	uint32_t *d_slots = nullptr, *d_seg_bytes = nullptr, *d_s1 = nullptr, *d_s2 = nullptr, *d_seg_off = nullptr;
+	uint32_t *d_slots = nullptr, *d_seg = nullptr; /* d_seg: bytes, s1, s2, offset, [nc * nseg] each */
+	uint32_t *d_ghist = nullptr, *d_tile_adler = nullptr;
+	SaZGroup *d_groups = nullptr;
 	uint8_t *d_out = nullptr;
-	size_t tile_bound = 0;
-	unsigned long long *d_tile_bytes = nullptr, *h_tile_bytes = nullptr;
-	uint8_t *h_buf = nullptr;
-	size_t h_cap = 0;
+	uint32_t *d_raw = nullptr; /* the row's raw tiles; level 0: the same memory as d_out */
+	size_t tile_bound = 0, row_bound = 0;
+	unsigned long long *d_info = nullptr; /* tile_bytes[nc], tile_base[nc + 1] */
+	unsigned long long *h_info[2] = {};
+	uint8_t *h_buf[2] = {};
+	size_t h_cap[2] = {};
+	bool two_buffers = false;
 	hipStream_t stream = nullptr;
-	int64_t encoded_row = -1; /* the tile row whose segments and offsets are in the device buffers (or on their way) */
+	int64_t launched_row = -1; /* the tile row that is encoded (or on its way), its copy enqueued */
+	size_t launched_copy = 0;  /* bytes of it that the enqueued copy covers                        */
+	size_t last_total = 0;
 	double encode_ms = 0, copy_ms = 0;
-	uint64_t raw_bytes = 0, out_bytes = 0;
+	uint64_t raw_bytes = 0, out_bytes = 0, late_bytes = 0;
 };
 
 static void zjob_free(sa_zjob *z)
@@ -381,17 +514,21 @@ static void zjob_free(sa_zjob *z)
 		(void)hipStreamDestroy(z->stream);
 	}
 	(void)hipFree(z->d_slots);
-	(void)hipFree(z->d_seg_bytes);
-	(void)hipFree(z->d_s1);
-	(void)hipFree(z->d_s2);
-	(void)hipFree(z->d_seg_off);
+	(void)hipFree(z->d_seg);
+	(void)hipFree(z->d_ghist);
+	(void)hipFree(z->d_tile_adler);
+	(void)hipFree(z->d_groups);
+	if (z->d_raw != reinterpret_cast<uint32_t *>(z->d_out))
+		(void)hipFree(z->d_raw);
 	(void)hipFree(z->d_out);
-	(void)hipFree(z->d_tile_bytes);
+	(void)hipFree(z->d_info);
 	(void)hipFree(z->d_owned);
-	if (z->h_tile_bytes)
-		(void)hipHostFree(z->h_tile_bytes);
-	if (z->h_buf)
-		(void)hipHostFree(z->h_buf);
+	for (int k = 0; k < 2; k++) {
+		if (z->h_info[k])
+			(void)hipHostFree(z->h_info[k]);
+		if (z->h_buf[k])
+			(void)hipHostFree(z->h_buf[k]);
+	}
 	if (z->ctx)
 		sa_ctx_destroy(z->ctx);
 	delete z;
@@ -399,6 +536,7 @@ static void zjob_free(sa_zjob *z)
 
 static SaZArgs zjob_args(const sa_zjob *z, int64_t row)
 {
+	const size_t segs = (size_t)z->nc * (size_t)z->nseg;
 	SaZArgs a{};
 	a.packed = z->d_packed;
 	a.full = z->d_full;
@@ -408,33 +546,67 @@ static SaZArgs zjob_args(const sa_zjob *z, int64_t row)
 	a.tile_row = (int32_t)row;
 	a.tile_col0 = 0;
 	a.nseg = z->nseg;
+	a.ngrp = z->ngrp;
 	a.slots = z->d_slots;
-	a.seg_bytes = z->d_seg_bytes;
-	a.seg_s1 = z->d_s1;
-	a.seg_s2 = z->d_s2;
+	a.seg_bytes = z->d_seg;
+	a.seg_s1 = z->d_seg ? z->d_seg + segs : nullptr;
+	a.seg_s2 = z->d_seg ? z->d_seg + 2 * segs : nullptr;
+	a.seg_off = z->d_seg ? z->d_seg + 3 * segs : nullptr;
+	a.ghist = z->d_ghist;
+	a.groups = z->d_groups;
+	a.tile_bytes = z->d_info;
+	a.tile_base = z->d_info ? z->d_info + z->nc : nullptr;
+	a.tile_adler = z->d_tile_adler;
+	a.out = z->d_out;
+	a.raw = z->d_raw;
 	return a;
 }
 
-/* segments + offsets of a tile row onto the job's stream; the sizes follow into page-locked memory */
-static bool zjob_encode(sa_zjob *z, int64_t row)
+static bool zjob_host_buffer(sa_zjob *z, int which, size_t bytes)
+{
+	if (bytes <= z->h_cap[which])
+		return true;
+	if (z->h_buf[which])
+		(void)hipHostFree(z->h_buf[which]);
+	z->h_buf[which] = nullptr;
+	z->h_cap[which] = 0;
+	const size_t want = std::min(z->row_bound, bytes + bytes / 16 + (1 << 20));
+	SA_HIP_CHECK(hipHostMalloc(&z->h_buf[which], want, hipHostMallocDefault), return false);
+	z->h_cap[which] = want;
+	return true;
+}
+
+/* Everything of a tile row onto the job's stream: encode (or tile), sizes, and a copy of the first `copy_bytes` of the
+ * row's compact buffer into host buffer `which` (0: the caller copies when it knows the length). */
+static bool zjob_launch(sa_zjob *z, int64_t row, int which, size_t copy_bytes)
 {
 	const SaZArgs a = zjob_args(z, row);
-	if (z->stored) {
-		hipLaunchKernelGGL(sa_k_tiles_stored, dim3((unsigned)z->chunk, (unsigned)z->nc), dim3(ZT), 0, z->stream, a,
-				   reinterpret_cast<uint32_t *>(z->d_out));
+	const dim3 per_seg((unsigned)z->nseg, (unsigned)z->nc), per_grp((unsigned)z->ngrp, (unsigned)z->nc);
+	hipLaunchKernelGGL(sa_k_tiles_raw, dim3((unsigned)z->chunk / 64, (unsigned)z->chunk / 64, (unsigned)z->nc), dim3(ZT), 0, z->stream, a);
+	SA_HIP_CHECK(hipGetLastError(), return false);
+	if (!z->stored) {
+		SA_HIP_CHECK(hipMemsetAsync(z->d_ghist, 0, sizeof(uint32_t) * (size_t)z->nc * (size_t)z->ngrp * ZHIST, z->stream), return false);
+		hipLaunchKernelGGL(sa_k_deflate_hist, per_seg, dim3(ZT), 0, z->stream, a);
 		SA_HIP_CHECK(hipGetLastError(), return false);
-		z->encoded_row = row;
-		return true;
+		hipLaunchKernelGGL(sa_k_deflate_codes, per_grp, dim3(ZT), 0, z->stream, a);
+		SA_HIP_CHECK(hipGetLastError(), return false);
+		hipLaunchKernelGGL(sa_k_deflate_encode, per_seg, dim3(ZT), 0, z->stream, a);
+		SA_HIP_CHECK(hipGetLastError(), return false);
+		hipLaunchKernelGGL(sa_k_deflate_offsets, dim3((unsigned)z->nc), dim3(ZT), 0, z->stream, a);
+		SA_HIP_CHECK(hipGetLastError(), return false);
+		hipLaunchKernelGGL(sa_k_deflate_rowbase, dim3(1), dim3(64), 0, z->stream, a, (int)z->nc);
+		SA_HIP_CHECK(hipGetLastError(), return false);
+		hipLaunchKernelGGL(sa_k_deflate_gather, per_seg, dim3(ZT), 0, z->stream, a);
+		SA_HIP_CHECK(hipGetLastError(), return false);
+		SA_HIP_CHECK(hipMemcpyAsync(z->h_info[which], z->d_info, sizeof(unsigned long long) * (size_t)(2 * z->nc + 1), hipMemcpyDeviceToHost,
+					    z->stream),
+			     return false);
 	}
-	hipLaunchKernelGGL(sa_k_deflate_segments, dim3((unsigned)z->nseg, (unsigned)z->nc), dim3(ZT), ZLDS_BYTES, z->stream, a);
-	SA_HIP_CHECK(hipGetLastError(), return false);
-	hipLaunchKernelGGL(sa_k_deflate_offsets, dim3((unsigned)z->nc), dim3(ZT), 0, z->stream, a, z->d_seg_off, z->d_out, z->tile_bound,
-			   z->d_tile_bytes);
-	SA_HIP_CHECK(hipGetLastError(), return false);
-	SA_HIP_CHECK(hipMemcpyAsync(z->h_tile_bytes, z->d_tile_bytes, sizeof(unsigned long long) * (size_t)z->nc, hipMemcpyDeviceToHost,
-				    z->stream),
-		     return false);
-	z->encoded_row = row;
+	if (copy_bytes) {
+		SA_HIP_CHECK(hipMemcpyAsync(z->h_buf[which], z->d_out, copy_bytes, hipMemcpyDeviceToHost, z->stream), return false);
+	}
+	z->launched_row = row;
+	z->launched_copy = copy_bytes;
 	return true;
 }
 
@@ -461,37 +633,37 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 	z->chunk_shift = shift;
 	z->nc = (int32_t)(((size_t)num + chunk_dim - 1) / chunk_dim);
 	z->nseg = (int32_t)((chunk_dim * chunk_dim + ZSEG - 1) / ZSEG);
+	z->ngrp = (z->nseg + ZGROUP - 1) / ZGROUP;
 	z->d_packed = d_packed;
 	z->d_full = d_packed ? nullptr : d_full;
 	z->stored = stored;
 	const size_t segs = (size_t)z->nc * (size_t)z->nseg;
-	/* a tile's stream at its very worst: header, 63 bits per element, the segments' ends */
-	z->tile_bound = (((size_t)z->nseg * ZSLOT_WORDS * 4 + 64) + 255) & ~(size_t)255;
-	if (stored)
-		z->tile_bound = chunk_dim * chunk_dim * sizeof(int32_t);
+	/* a tile's stream at its very worst (header, 63 bits per element, the segments' ends), on a 64-byte boundary */
+	z->tile_bound = stored ? chunk_dim * chunk_dim * sizeof(int32_t) : (((size_t)z->nseg * ZSLOT_WORDS * 4 + 64) + 255) & ~(size_t)255;
+	z->row_bound = (size_t)z->nc * z->tile_bound;
+	/* a second host buffer lets row r + 1 be copied while the caller writes row r; page-locking it costs ~0.1 ms per MB,
+	 * the copies it hides ~0.02 ms per MB and row: worth it from eight tile rows on */
+	z->two_buffers = z->nc >= 8;
 	bool ok = false;
 	do {
 		SA_HIP_CHECK(hipStreamCreateWithFlags(&z->stream, hipStreamNonBlocking), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_out, (size_t)z->nc * z->tile_bound), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_out, z->row_bound), break);
 		if (stored) {
+			z->d_raw = reinterpret_cast<uint32_t *>(z->d_out);
 			ok = true;
 			break;
 		}
-		static std::atomic<unsigned long long> raised{ 0 }; /* bit d: more than 64 KB of dynamic LDS opted into on device d */
-		const unsigned long long bit = 1ull << (device & 63);
-		if (!(raised.load() & bit)) {
-			SA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&sa_k_deflate_segments),
-							 hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZLDS_BYTES),
-				     break);
-			raised.fetch_or(bit);
-		}
+		SA_HIP_CHECK(hipMalloc(&z->d_raw, (size_t)z->nc * chunk_dim * chunk_dim * sizeof(uint32_t)), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_slots, segs * ZSLOT_WORDS * sizeof(uint32_t)), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_seg_bytes, segs * sizeof(uint32_t)), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_s1, segs * sizeof(uint32_t)), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_s2, segs * sizeof(uint32_t)), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_seg_off, segs * sizeof(uint32_t)), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_tile_bytes, sizeof(unsigned long long) * (size_t)z->nc), break);
-		SA_HIP_CHECK(hipHostMalloc(&z->h_tile_bytes, sizeof(unsigned long long) * (size_t)z->nc, hipHostMallocDefault), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_seg, 4 * segs * sizeof(uint32_t)), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_ghist, sizeof(uint32_t) * (size_t)z->nc * (size_t)z->ngrp * ZHIST), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_groups, sizeof(SaZGroup) * (size_t)z->nc * (size_t)z->ngrp), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_tile_adler, sizeof(uint32_t) * (size_t)z->nc), break);
+		SA_HIP_CHECK(hipMalloc(&z->d_info, sizeof(unsigned long long) * (size_t)(2 * z->nc + 1)), break);
+		for (int k = 0; k < 2; k++)
+			SA_HIP_CHECK(hipHostMalloc(&z->h_info[k], sizeof(unsigned long long) * (size_t)(2 * z->nc + 1), hipHostMallocDefault), break);
+		if (!z->h_info[0] || !z->h_info[1])
+			break;
 		ok = true;
 	} while (0);
 	if (!ok) {
@@ -521,51 +693,73 @@ extern "C" int sa_zjob_tile_row(sa_zjob *z, size_t tile_row, const uint8_t **str
 			return 1;
 		}
 		SA_HIP_CHECK(hipSetDevice(z->device), return 1);
+		const int which = z->two_buffers ? (int)(tile_row & 1) : 0;
 		const auto t0 = std::chrono::steady_clock::now();
-		if (z->encoded_row != (int64_t)tile_row && !zjob_encode(z, (int64_t)tile_row))
-			return 1;
-		SA_HIP_CHECK(hipStreamSynchronize(z->stream), return 1); /* the sizes are here */
+		if (z->launched_row != (int64_t)tile_row) { /* the first row, or rows asked for out of order: nothing is on its way */
+			size_t copy = 0;
+			if (z->stored) {
+				copy = z->row_bound;
+				if (!zjob_host_buffer(z, which, copy))
+					return 1;
+			}
+			if (!zjob_launch(z, (int64_t)tile_row, which, copy))
+				return 1;
+		}
+		SA_HIP_CHECK(hipStreamSynchronize(z->stream), return 1);
 		z->encode_ms += sa_ms_since(t0);
 		const auto t1 = std::chrono::steady_clock::now();
-		size_t total = 0;
-		for (int t = 0; t < z->nc; t++) {
-			sizes[t] = z->stored ? z->tile_bound : (size_t)z->h_tile_bytes[t];
-			if (sizes[t] > z->tile_bound) {
-				sa_set_error("sa_zjob_tile_row: a tile's stream outgrew its bound (%zu > %zu)", sizes[t], z->tile_bound);
+		size_t total = z->row_bound;
+		if (!z->stored) {
+			const unsigned long long *info = z->h_info[which];
+			total = (size_t)info[2 * z->nc];
+			if (total > z->row_bound) {
+				sa_set_error("sa_zjob_tile_row: a tile row outgrew its bound (%zu > %zu)", total, z->row_bound);
 				return 1;
 			}
-			total += (sizes[t] + 63) & ~(size_t)63;
-		}
-		if (total > z->h_cap) {
-			if (z->h_buf)
-				(void)hipHostFree(z->h_buf);
-			z->h_buf = nullptr;
-			z->h_cap = 0;
-			const size_t want = total + total / 8 + (1 << 20);
-			SA_HIP_CHECK(hipHostMalloc(&z->h_buf, want, hipHostMallocDefault), return 1);
-			z->h_cap = want;
-		}
-		if (!z->stored) {
-			const SaZArgs a = zjob_args(z, (int64_t)tile_row);
-			hipLaunchKernelGGL(sa_k_deflate_gather, dim3((unsigned)z->nseg, (unsigned)z->nc), dim3(ZT), 0, z->stream, a, z->d_seg_off,
-					   z->d_out, z->tile_bound);
-			SA_HIP_CHECK(hipGetLastError(), return 1);
-		}
-		size_t at = 0;
-		for (int t = 0; t < z->nc; t++) {
-			SA_HIP_CHECK(hipMemcpyAsync(z->h_buf + at, z->d_out + (size_t)t * z->tile_bound, sizes[t], hipMemcpyDeviceToHost, z->stream),
-				     return 1);
-			streams[t] = z->h_buf + at;
-			at += (sizes[t] + 63) & ~(size_t)63;
-			z->out_bytes += sizes[t];
+			if (total > z->launched_copy) { /* what the enqueued copy did not cover (the first row: everything) */
+				size_t have = z->launched_copy;
+				if (total > z->h_cap[which]) { /* (a new buffer: the part already copied is copied again) */
+					if (!zjob_host_buffer(z, which, total))
+						return 1;
+					have = 0;
+				}
+				SA_HIP_CHECK(hipMemcpyAsync(z->h_buf[which] + have, z->d_out + have, total - have, hipMemcpyDeviceToHost, z->stream), return 1);
+				SA_HIP_CHECK(hipStreamSynchronize(z->stream), return 1);
+				z->late_bytes += total - have;
+			}
+			for (int t = 0; t < z->nc; t++) {
+				sizes[t] = (size_t)info[t];
+				streams[t] = z->h_buf[which] + (size_t)info[z->nc + t];
+				z->out_bytes += sizes[t];
+			}
+		} else {
+			for (int t = 0; t < z->nc; t++) {
+				sizes[t] = z->tile_bound;
+				streams[t] = z->h_buf[which] + (size_t)t * z->tile_bound;
+				z->out_bytes += sizes[t];
+			}
 		}
 		z->raw_bytes += (uint64_t)z->nc * (uint64_t)z->chunk * (uint64_t)z->chunk * 4u;
-		SA_HIP_CHECK(hipStreamSynchronize(z->stream), return 1);
+		z->last_total = total;
 		z->copy_ms += sa_ms_since(t1);
-		/* the next row is encoded while the caller writes this one (its sizes land in h_tile_bytes, which the caller no
-		 * longer needs: sizes[] is its own copy) */
-		if (tile_row + 1 < (size_t)z->nc && !zjob_encode(z, (int64_t)tile_row + 1))
-			return 1;
+		/* the next row is encoded and copied while the caller writes this one.  With one host buffer the copy would
+		 * overwrite what the caller is about to read: then only the encoding runs ahead. */
+		if (tile_row + 1 < (size_t)z->nc) {
+			const int next = z->two_buffers ? (int)((tile_row + 1) & 1) : 0;
+			size_t copy = 0;
+			if (z->two_buffers) {
+				copy = z->stored ? z->row_bound : std::min(z->row_bound, total + total / 32 + (1 << 16));
+				if (!zjob_host_buffer(z, next, copy))
+					return 1;
+			}
+			if (!z->two_buffers && z->stored) {
+				/* (raw tiles, one buffer: the kernel may run ahead, the copy waits for the next call) */
+				z->launched_row = -1;
+				return 0;
+			}
+			if (!zjob_launch(z, (int64_t)tile_row + 1, next, copy))
+				return 1;
+		}
 		return 0;
 	});
 }

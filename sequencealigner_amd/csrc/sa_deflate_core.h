@@ -30,7 +30,8 @@ enum : int {
 	SA_Z_EOB = 256,   /* end of block                                                */
 	SA_Z_LEN3 = 257,  /* match length 3 (no extra bits)                              */
 	SA_Z_J = 8,       /* elements a match may reach back (distance 4 .. 32 bytes)    */
-	SA_Z_ELEM_BITS = 63 /* an element never takes more: 4 x 15, or 15 + 15 + 15 + 3    */
+	SA_Z_ELEM_BITS = 63, /* an element never takes more: 4 x 15, or 15 + 15 + 15 + 3   */
+	SA_Z_HEADER_BITS = 4544 /* a block header never takes more: 17 + 19 x 3 + 316 x (7 + 7) */
 };
 
 /* distance 4 j, j = 1..8: code (RFC 1951 3.2.5), number of extra bits, their value -- a nibble per j */
@@ -87,9 +88,9 @@ SA_HD inline int sa_z_sort_small(const uint32_t *freq, int n, uint16_t *order)
 
 /* Code lengths (<= maxbits) of a Huffman code over order[0..used) (ascending weight, used >= 2); len[] of every other
  * symbol is left alone.  Two queues (the sorted leaves, the internal nodes in the order they are made: both ascending),
- * depths from the root down, and where the tree is deeper than maxbits the classic repair on the count of codes per
- * length: a leaf one level above the limit takes an overflowing leaf as its sibling, until nothing overflows; lengths
- * are then dealt out again, longest to the lightest symbol (Kraft sum exactly 1, checked by the harness). */
+ * depths from the root down; leaves deeper than maxbits are counted at maxbits, which oversubscribes the code by a whole
+ * number of units of 2^-maxbits, and the count of codes per length is repaired one unit at a time (below); lengths are
+ * then dealt out again, longest to the lightest symbol (Kraft sum exactly 1, checked by the harness). */
 SA_HD inline void sa_z_lengths(const uint32_t *freq, const uint16_t *order, int used, int maxbits, uint8_t *len, uint32_t *w,
 			       uint16_t *par, uint16_t *bl)
 {
@@ -247,9 +248,9 @@ SA_HD inline void sa_z_header(SaZWork &W, SaZBits &b, bool final_block)
 
 /* the end of a segment: end-of-block, then an empty stored block -- three header bits, padding to the byte, 00 00 ff ff.
  * Returns the segment's length in bytes. */
-SA_HD inline uint32_t sa_z_finish_segment(SaZWork &W, SaZBits &b)
+SA_HD inline uint32_t sa_z_finish_segment(const uint32_t *lcode, SaZBits &b)
 {
-	const uint32_t c = W.lcode[SA_Z_EOB];
+	const uint32_t c = lcode[SA_Z_EOB];
 	sa_z_put(b, c & 0xffffu, c >> 16);
 	sa_z_put(b, 0u, 3);
 	b.pos = (b.pos + 7u) & ~7u;
@@ -269,23 +270,23 @@ SA_HD inline int sa_z_match(const uint32_t *e, uint32_t k)
 }
 
 /* the bits of one element (LSB first) under the segment's codes; returns their number (<= SA_Z_ELEM_BITS) */
-SA_HD inline uint32_t sa_z_element(const SaZWork &W, uint32_t v, int j, uint64_t *bits)
+SA_HD inline uint32_t sa_z_element(const uint32_t *lcode, const uint32_t *dcode, uint32_t v, int j, uint64_t *bits)
 {
-	uint32_t c = W.lcode[v & 255u];
+	uint32_t c = lcode[v & 255u];
 	uint64_t acc = c & 0xffffu;
 	uint32_t n = c >> 16;
 	if (j) {
-		c = W.lcode[SA_Z_LEN3];
+		c = lcode[SA_Z_LEN3];
 		acc |= (uint64_t)(c & 0xffffu) << n;
 		n += c >> 16;
-		c = W.dcode[sa_z_dcode(j)];
+		c = dcode[sa_z_dcode(j)];
 		acc |= (uint64_t)(c & 0xffffu) << n;
 		n += c >> 16;
 		acc |= (uint64_t)sa_z_dext_val(j) << n;
 		n += sa_z_dext_bits(j);
 	} else {
 		for (int t = 1; t < 4; t++) {
-			c = W.lcode[(v >> (8 * t)) & 255u];
+			c = lcode[(v >> (8 * t)) & 255u];
 			acc |= (uint64_t)(c & 0xffffu) << n;
 			n += c >> 16;
 		}

@@ -50,12 +50,12 @@ def contents(kind: str, rng) -> np.ndarray:
 
 
 @pytest.mark.parametrize("kind", ["scores", "zeros", "constant", "full_range", "positive_small", "geometric", "one_element", "high_parts"])
-@pytest.mark.parametrize("segment", [16384, 777])
-def test_streams_inflate_to_the_input(kind, segment, harness, tmp_path):
+@pytest.mark.parametrize("segment,group", [(16384, 1), (777, 1), (2048, 16)])
+def test_streams_inflate_to_the_input(kind, segment, group, harness, tmp_path):
     data = contents(kind, np.random.default_rng(len(kind) * 1000 + segment))
     src, dst = tmp_path / "in.i32", tmp_path / "out.zz"
     data.astype("<i4").tofile(src)
-    res = subprocess.run([str(harness), str(src), str(dst), str(segment)], capture_output=True, text=True)
+    res = subprocess.run([str(harness), str(src), str(dst), str(segment), str(group)], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "ERROR: AddressSanitizer" not in res.stderr and "runtime error" not in res.stderr, res.stderr
     z = dst.read_bytes()
