@@ -641,9 +641,10 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 	/* a tile's stream at its very worst (header, 63 bits per element, the segments' ends), on a 64-byte boundary */
 	z->tile_bound = stored ? chunk_dim * chunk_dim * sizeof(int32_t) : (((size_t)z->nseg * ZSLOT_WORDS * 4 + 64) + 255) & ~(size_t)255;
 	z->row_bound = (size_t)z->nc * z->tile_bound;
-	/* a second host buffer lets row r + 1 be copied while the caller writes row r; page-locking it costs ~0.1 ms per MB,
-	 * the copies it hides ~0.02 ms per MB and row: worth it from eight tile rows on */
-	z->two_buffers = z->nc >= 8;
+	/* a second host buffer lets row r + 1 be copied while the caller writes row r; page-locking it costs ~0.1-0.2 ms per MB,
+	 * the copies it hides ~0.02 ms per MB and row: worth it from eight tile rows on -- for streams.  Raw tiles are three
+	 * times the bytes per row: config 4 (13 rows of 872 MB) measured 1.50 s with one buffer, 1.83 s with two. */
+	z->two_buffers = !stored && z->nc >= 8;
 	bool ok = false;
 	do {
 		SA_HIP_CHECK(hipStreamCreateWithFlags(&z->stream, hipStreamNonBlocking), break);
