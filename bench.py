@@ -325,6 +325,53 @@ def s32_kernels_leg(seqs, cfg, steps: int, torch, sa) -> dict:
         dest.close()
 
 
+def deflate_leg(seqs, cfg, torch, sa) -> dict:
+    """the `-z` path of the tool on the headline workload: the N x N matrix as HDF5 chunks (4096 x 4096), deflated on the device
+    (csrc/sa_deflate.hip).  Every tile is inflated with stock zlib and compared with the matrix the CPU scores give (the
+    reference's own when the headline leg ran it), zero diagonal and zero padding included."""
+    import zlib
+    import numpy as np
+    store = sa.SequenceStore.from_sequences(seqs)
+    scoring = sa.Scoring.from_names(cfg["method"], cfg["matrix"], **cfg["gaps"])
+    n, chunk = store.num, 4096
+    d = torch.empty(store.pairs, dtype=torch.int32, device="cuda")
+    with sa.Context(store, scoring, 0) as ctx:
+        ctx.align_range(0, store.pairs, d.data_ptr())
+        torch.cuda.synchronize()
+    against = "device scores"
+    tri = None
+    if "cfg2" in _cpu_scores and _cpu_scores["cfg2"][0] == n:
+        tri, against = _cpu_scores["cfg2"][1], _cpu_scores["cfg2"][2]
+    if tri is None:
+        tri = d.cpu().numpy()
+    out = {"chunk": chunk, "level": "fixed parse + dynamic Huffman (DESIGN.md 4.8)"}
+    for trial in range(2):  # (the second walk is the timed one: buffers page-locked, code objects loaded)
+        with sa.DeflateJob(n, chunk, d_packed_ptr=d.data_ptr()) as job:
+            t0 = time.perf_counter()
+            rows = [job.tile_row(r) for r in range(job.tiles_per_row)]
+            wall = time.perf_counter() - t0
+            st = job.stats()
+    nc = len(rows)
+    mism = tiles = 0
+    jj = np.repeat(np.arange(n), np.arange(n))
+    ii = np.concatenate([np.arange(k) for k in range(n)])
+    full = np.zeros((nc * chunk, nc * chunk), np.int32)
+    full[ii, jj] = tri
+    full[jj, ii] = tri
+    for r in range(nc):
+        for c in range(nc):
+            got = np.frombuffer(zlib.decompress(rows[r][c]), "<i4").reshape(chunk, chunk)
+            mism += int(np.count_nonzero(got != full[r * chunk:(r + 1) * chunk, c * chunk:(c + 1) * chunk]))
+            tiles += 1
+    out.update({"raw_bytes": st["raw_bytes"], "stream_bytes": st["out_bytes"], "ratio": st["raw_bytes"] / st["out_bytes"],
+                "walk_seconds": wall, "matrix_gb_per_s": st["raw_bytes"] / wall / 1e9,
+                "note": "walk = encode + gather + device->host copy + the binding's copy of every stream into Python bytes; the kernels "
+                        "alone: profiles/r04d_deflate_encoder_summary.txt",
+                "parity": {"tiles_inflated": tiles, "elements_compared": tiles * chunk * chunk, "mismatches": mism, "against": against,
+                           "compared": "zlib.decompress of every tile vs the full symmetric matrix of the CPU scores (zero diagonal, zero padding)"}})
+    return out
+
+
 _json_fd = None
 
 
@@ -461,7 +508,9 @@ def main():
             extra["mixed"] = extra_config("mixed", None, 3, cpu_s, args.cpu_full_seconds, torch, sa, make_config)
             out["extra"] = {"configs": extra,
                             # the same cfg 2 step with the packed kernels switched off: the reference-width (s32) systolic kernels
-                            "s32_kernels": s32_kernels_leg(seqs, cfg, 3, torch, sa)}
+                            "s32_kernels": s32_kernels_leg(seqs, cfg, 3, torch, sa),
+                            # the -z path: the matrix as HDF5 chunks deflated on the device, every tile inflated and compared
+                            "deflate": deflate_leg(seqs, cfg, torch, sa)}
         emit(out)
         return
 

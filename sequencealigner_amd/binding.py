@@ -53,6 +53,7 @@ ABI_SYMBOLS = (
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
     "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown", "sa_ctx_leave_room", "sa_hip_set_progress",
     "sa_hip_last_align_path",
+    "sa_zjob_create", "sa_zjob_destroy", "sa_zjob_tiles_per_row", "sa_zjob_tile_row", "sa_zjob_stats", "sa_hip_deflate_begin",
 )
 
 
