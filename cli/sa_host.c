@@ -688,7 +688,7 @@ static int open_output(const char *path, const struct sa_host_store *s, unsigned
 /* Output whose tiles arrive finished (sa_zjob_tile_row of include/seqalign_hip.h): zlib streams from the device-side encoder
  * when `compression` > 0, the raw tiles when 0.  Same file, dataset, chunk shape and filter pipeline as sa_host_write_hdf5 --
  * the tiles go to H5Dwrite_chunk as they are, tile row after tile row. */
-int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tile_row_fn next,
+int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tiles_fn next,
 			       void *user)
 {
 	const size_t dim = (size_t)s->in.num;
@@ -701,18 +701,26 @@ int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, 
 	const size_t nc = (dim + chunk - 1) / chunk;
 	const uint8_t **streams = malloc(sizeof(*streams) * nc);
 	size_t *sizes = malloc(sizeof(*sizes) * nc);
-	int rc = streams && sizes ? 0 : fail("Out of memory during HDF5 conversion");
-	for (size_t r = 0; r < nc && !rc; r++) {
-		if (next(user, r, streams, sizes)) {
-			rc = fail("Failed to encode tile row %zu of the Similarity Matrix", r);
+	uint32_t *rows = malloc(sizeof(*rows) * nc), *cols = malloc(sizeof(*cols) * nc);
+	int rc = streams && sizes && rows && cols ? 0 : fail("Out of memory during HDF5 conversion");
+	size_t written = 0;
+	while (!rc) {
+		const int n = next(user, rows, cols, streams, sizes);
+		if (n < 0)
+			rc = fail("Failed to encode tiles of the Similarity Matrix");
+		if (n <= 0)
 			break;
-		}
-		for (size_t c = 0; c < nc && !rc; c++) {
-			hsize_t pos[2] = { r * chunk, c * chunk };
-			if (H5Dwrite_chunk(mset, H5P_DEFAULT, 0, pos, sizes[c], streams[c]) < 0)
+		for (int t = 0; t < n && !rc; t++) {
+			hsize_t pos[2] = { (hsize_t)rows[t] * chunk, (hsize_t)cols[t] * chunk };
+			if (rows[t] >= nc || cols[t] >= nc || H5Dwrite_chunk(mset, H5P_DEFAULT, 0, pos, sizes[t], streams[t]) < 0)
 				rc = fail("Failed to write chunk to HDF5");
 		}
+		written += (size_t)n;
 	}
+	if (!rc && written != nc * nc)
+		rc = fail("The Similarity Matrix has %zu tiles, %zu were delivered", nc * nc, written);
+	free(cols);
+	free(rows);
 	free(sizes);
 	free(streams);
 	H5Dclose(mset);

@@ -66,11 +66,12 @@ int sa_host_write_hdf5(const char *path, const struct sa_host_store *s, const in
 		       unsigned compression);
 size_t sa_host_hdf5_chunk_dim(size_t dim); /* exposed for tests */
 /* ... and the same file from tiles that arrive finished -- zlib streams from the device-side encoder of the -z option, or
- * (compression 0) the raw tiles; include/seqalign_hip.h: sa_zjob_tile_row has exactly this signature:
- * next(user, r, streams, sizes) fills the ceil(N / chunk) tiles of tile row r, valid until its next call; they go to
- * H5Dwrite_chunk unchanged. */
-typedef int (*sa_host_tile_row_fn)(void *user, size_t tile_row, const uint8_t **streams, size_t *sizes);
-int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tile_row_fn next,
+ * (compression 0) the raw tiles; include/seqalign_hip.h: sa_zjob_next has exactly this signature:
+ * next(user, rows, cols, streams, sizes) fills the next batch of at most ceil(N / chunk) tiles (tile coordinates + bytes,
+ * valid until its next call) and returns their number, 0 at the end, < 0 on error; the tiles go to H5Dwrite_chunk unchanged,
+ * in whatever order they come. */
+typedef int (*sa_host_tiles_fn)(void *user, uint32_t *rows, uint32_t *cols, const uint8_t **streams, size_t *sizes);
+int sa_host_write_hdf5_streams(const char *path, const struct sa_host_store *s, unsigned compression, sa_host_tiles_fn next,
 			       void *user);
 
 #ifdef __cplusplus

@@ -203,18 +203,29 @@ int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t *d_full, vo
  * on score matrices sits between zlib -1 and -6, whatever level > 0 the dataset's property list names.  Level 0 returns the
  * tiles as they are (chunk_dim^2 int32 each), for a chunked dataset without filters: the same H5Dwrite_chunk loop then
  * replaces H5Dwrite's gather of every tile out of N-wide rows in the writing thread (hdf5.c:148-194).
- *   sa_zjob_create       buffers for one tile row; chunk_dim: a power of two in [64, 4096] (sa_host_hdf5_chunk_dim)
+ *   sa_zjob_create       buffers for one line of tiles; chunk_dim: a power of two in [64, 4096] (sa_host_hdf5_chunk_dim)
  *   sa_zjob_tile_row     streams[t] / sizes[t] for the tiles_per_row tiles of row `tile_row`, valid until the next call;
- *                        rows are meant to be asked for in order: the next row is encoded while the caller writes
- *   sa_hip_deflate_begin sa_ctx_create + all pairs into device memory + sa_zjob_create on device 0; *align_seconds = the
- *                        launch loop alone (the bracket of sa_hip_last_align_seconds).  NULL + sa_last_error on failure. */
+ *                        rows are asked for in order, each once: the next row is encoded while the caller writes
+ *   sa_hip_tiles_begin   sa_ctx_create + the packed matrix in device memory + a job on device 0 that walks the tiles in
+ *                        SHELLS while the alignment is still running: the tiles whose larger tile index is b need exactly
+ *                        the columns [b * chunk_dim, (b + 1) * chunk_dim), so they are encoded and handed out while the
+ *                        device aligns the next column blocks (the alignment phase and the reference's output phase,
+ *                        src/main.c:31-34, overlap).  The first blocks are on their way when it returns.
+ *   sa_zjob_next         the next batch of finished tiles (at most tiles_per_row): rows[t], cols[t] = tile coordinates,
+ *                        streams[t] / sizes[t] valid until the next call; returns their number, 0 when every tile has been
+ *                        handed out, < 0 on error.  Works on a sa_zjob_create job as well (then: row after row).
+ *   sa_zjob_align_seconds  device time of the alignment so far (sum over the finished column blocks: the bracket of
+ *                        sa_hip_last_align_seconds).
+ * NULL / non-zero + sa_last_error on failure. */
 typedef struct sa_zjob sa_zjob;
 sa_zjob *sa_zjob_create(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim, int level);
 size_t sa_zjob_tiles_per_row(const sa_zjob *job);
 int sa_zjob_tile_row(sa_zjob *job, size_t tile_row, const uint8_t **streams, size_t *sizes);
+int sa_zjob_next(sa_zjob *job, uint32_t *rows, uint32_t *cols, const uint8_t **streams, size_t *sizes);
 void sa_zjob_stats(const sa_zjob *job, double *encode_ms, double *copy_ms, uint64_t *raw_bytes, uint64_t *out_bytes);
+double sa_zjob_align_seconds(const sa_zjob *job);
 void sa_zjob_destroy(sa_zjob *job);
-sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level, double *align_seconds);
+sa_zjob *sa_hip_tiles_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level);
 
 /* ---- pair-space planning (host only, no device needed) -------------------
  * DP cells (sum of len_i*len_j) of the packed pair range [start, start+count),

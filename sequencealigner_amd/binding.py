@@ -53,7 +53,7 @@ ABI_SYMBOLS = (
     "sa_hip_last_align_seconds", "sa_ctx_align_host", "sa_hip_host_register", "sa_hip_host_unregister",
     "sa_ctx_share_elems", "sa_ctx_align_share", "sa_ctx_place_shares", "sa_hip_last_align_breakdown", "sa_ctx_leave_room", "sa_hip_set_progress",
     "sa_hip_last_align_path",
-    "sa_zjob_create", "sa_zjob_destroy", "sa_zjob_tiles_per_row", "sa_zjob_tile_row", "sa_zjob_stats", "sa_hip_deflate_begin",
+    "sa_zjob_create", "sa_zjob_destroy", "sa_zjob_tiles_per_row", "sa_zjob_tile_row", "sa_zjob_stats", "sa_zjob_next", "sa_zjob_align_seconds", "sa_hip_tiles_begin",
 )
 
 
@@ -170,6 +170,12 @@ def load_library() -> C.CDLL:
     lib.sa_zjob_tile_row.restype = C.c_int
     lib.sa_zjob_stats.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     lib.sa_zjob_stats.restype = None
+    lib.sa_zjob_next.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.sa_zjob_next.restype = C.c_int
+    lib.sa_zjob_align_seconds.argtypes = [C.c_void_p]
+    lib.sa_zjob_align_seconds.restype = C.c_double
+    lib.sa_hip_tiles_begin.argtypes = [_Input, C.POINTER(_Scoring), C.c_size_t, C.c_int]
+    lib.sa_hip_tiles_begin.restype = C.c_void_p
     _lib = lib
     return lib
 
@@ -549,13 +555,39 @@ class DeflateJob:
     the full symmetric matrix as zlib streams (level > 0) or as they are (level 0).  d_packed_ptr: scores by packed pair
     index; or d_full_ptr: N x N."""
 
-    def __init__(self, num: int, chunk_dim: int, d_packed_ptr: int = 0, d_full_ptr: int = 0, device: int = 0, level: int = 6):
+    def __init__(self, num: int, chunk_dim: int, d_packed_ptr: int = 0, d_full_ptr: int = 0, device: int = 0, level: int = 6, _handle=None):
         self._lib = load_library()
-        self._h = self._lib.sa_zjob_create(int(device), C.c_void_p(d_packed_ptr or None), C.c_void_p(d_full_ptr or None),
-                                           int(num), int(chunk_dim), int(level))
+        self._h = _handle or self._lib.sa_zjob_create(int(device), C.c_void_p(d_packed_ptr or None), C.c_void_p(d_full_ptr or None),
+                                                      int(num), int(chunk_dim), int(level))
         if not self._h:
             raise AlignError(_err())
         self.tiles_per_row = int(self._lib.sa_zjob_tiles_per_row(self._h))
+
+    @classmethod
+    def begin(cls, store: "SequenceStore", scoring: "Scoring", chunk_dim: int, level: int = 6) -> "DeflateJob":
+        """sa_hip_tiles_begin: the alignment of `store` runs on device 0 while next() hands out the finished tiles shell by shell"""
+        lib = load_library()
+        sc = scoring._as_c()
+        h = lib.sa_hip_tiles_begin(store._as_c(), C.byref(sc), int(chunk_dim), int(level))
+        if not h:
+            raise AlignError(_err())
+        job = cls(store.num, chunk_dim, _handle=h)
+        job._store = store  # keep the host arrays alive
+        return job
+
+    def next(self) -> list[tuple[int, int, bytes]]:
+        """the next batch of finished tiles as (tile row, tile column, bytes); [] when every tile has been handed out"""
+        n = self.tiles_per_row
+        rows, cols = (C.c_uint32 * n)(), (C.c_uint32 * n)()
+        ptrs, sizes = (C.c_void_p * n)(), (C.c_size_t * n)()
+        got = self._lib.sa_zjob_next(self._h, rows, cols, ptrs, sizes)
+        if got < 0:
+            raise AlignError(_err())
+        return [(int(rows[t]), int(cols[t]), C.string_at(ptrs[t], sizes[t])) for t in range(got)]
+
+    @property
+    def align_seconds(self) -> float:
+        return float(self._lib.sa_zjob_align_seconds(self._h))
 
     def tile_row(self, row: int) -> list[bytes]:
         """the zlib streams of tile row `row` (copied out of the job's page-locked buffer)"""

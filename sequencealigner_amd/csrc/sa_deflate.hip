@@ -32,6 +32,8 @@
  */
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "sa_ctx.h"
@@ -60,7 +62,7 @@ struct SaZArgs {
 	const int32_t *packed; /* scores by packed pair index j (j - 1) / 2 + i, i < j (src/io/output.c:76-83)     */
 	const int32_t *full;   /* ... or the full num x num matrix (packed == nullptr)                              */
 	int32_t num, chunk, chunk_shift;
-	int32_t tile_row, tile_col0;
+	int32_t tile_r0, tile_c0, tile_dr, tile_dc; /* tile t of the batch is (tile_r0 + t * tile_dr, tile_c0 + t * tile_dc) */
 	int32_t nseg, ngrp;    /* segments / code groups per tile                                                   */
 	uint32_t *slots;       /* [tile][segment][ZSLOT_WORDS]                                                      */
 	uint32_t *seg_bytes, *seg_s1, *seg_s2, *seg_off; /* [tile][segment]                                        */
@@ -458,7 +460,7 @@ __global__ __launch_bounds__(ZT) void sa_k_tiles_raw(SaZArgs A)
 	__shared__ uint32_t turn[64][65];
 	const int tile = blockIdx.z, tid = threadIdx.x;
 	const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-	const int64_t i0 = (int64_t)A.tile_row * A.chunk + r0, j0 = (int64_t)(A.tile_col0 + tile) * A.chunk + c0;
+	const int64_t i0 = (int64_t)(A.tile_r0 + tile * A.tile_dr) * A.chunk + r0, j0 = (int64_t)(A.tile_c0 + tile * A.tile_dc) * A.chunk + c0;
 	uint32_t *const o = A.raw + (size_t)tile * (size_t)A.chunk * (size_t)A.chunk + (size_t)r0 * (size_t)A.chunk + (size_t)c0;
 	const int x = tid & 63, y4 = tid >> 6;
 	if (A.packed && j0 >= i0 + 64) { /* strictly above the diagonal: element (i, j) = packed[tri(j) + i] */
@@ -478,28 +480,49 @@ __global__ __launch_bounds__(ZT) void sa_k_tiles_raw(SaZArgs A)
 } // namespace
 
 /* ---- host side ---------------------------------------------------------------------------------------------------- */
+/* A BATCH is what one pass of the kernels encodes: up to nc tiles in a line -- a tile row (the walk over a finished matrix,
+ * sa_zjob_tile_row), or, while the alignment is still running (sa_hip_tiles_begin / sa_zjob_next), the two arms of a SHELL:
+ * the tiles whose larger tile index is b need exactly the columns of column block b, so they can be encoded and written while
+ * the device aligns block b + 1:  batch 2 b - 1 = (b, 0) .. (b, b),  batch 2 b = (0, b) .. (b - 1, b)  (b = 0: the tile (0, 0)). */
+struct SaZBatch {
+	int32_t r0 = 0, c0 = 0, dr = 0, dc = 0, nt = 0;
+	int32_t block = -1; /* the column block whose alignment it waits for (-1: none) */
+};
+
 struct sa_zjob {
 	int device = 0;
 	int32_t num = 0, chunk = 0, chunk_shift = 0, nc = 0, nseg = 0, ngrp = 0;
 	bool stored = false; /* level 0: raw tiles */
 	const int32_t *d_packed = nullptr, *d_full = nullptr;
-	int32_t *d_owned = nullptr; /* the packed matrix, when the job made it (sa_hip_deflate_begin) */
+	int32_t *d_owned = nullptr; /* the packed matrix, when the job made it (sa_hip_tiles_begin) */
 	sa_ctx *ctx = nullptr;
 	uint32_t *d_slots = nullptr, *d_seg = nullptr; /* d_seg: bytes, s1, s2, offset, [nc * nseg] each */
 	uint32_t *d_ghist = nullptr, *d_tile_adler = nullptr;
 	SaZGroup *d_groups = nullptr;
-	uint8_t *d_out = nullptr;
-	uint32_t *d_raw = nullptr; /* the row's raw tiles; level 0: the same memory as d_out */
+	/* what a batch leaves for its copy, twice (batch id uses [id & 1]): the next batch is encoded while this one's copy runs */
+	uint8_t *d_out[2] = {};
+	unsigned long long *d_info[2] = {}; /* tile_bytes[nc], tile_base[nc + 1] */
+	uint32_t *d_raw = nullptr; /* the batch's raw tiles (level 0: d_out itself) */
 	size_t tile_bound = 0, row_bound = 0;
-	unsigned long long *d_info = nullptr; /* tile_bytes[nc], tile_base[nc + 1] */
 	unsigned long long *h_info[2] = {};
 	uint8_t *h_buf[2] = {};
 	size_t h_cap[2] = {};
+	size_t host_estimate = 0; /* bytes of the largest batch to come, as far as known */
 	bool two_buffers = false;
-	hipStream_t stream = nullptr;
-	int64_t launched_row = -1; /* the tile row that is encoded (or on its way), its copy enqueued */
-	size_t launched_copy = 0;  /* bytes of it that the enqueued copy covers                        */
-	size_t last_total = 0;
+	/* ONE in-order stream carries the alignment's launches and the encoder's kernels -- the alignment's persistent workgroups
+	 * fill every CU for the whole of a launch (all VGPRs at four waves per SIMD, or all LDS), so on a stream of its own the
+	 * encoder only ever ran when a launch drained, a column block late; in order it runs between two launches, alone, for a few
+	 * milliseconds.  The copies have their own stream. */
+	hipStream_t stream = nullptr, copy_stream = nullptr;
+	hipEvent_t enc_done[2] = {};
+	int64_t enc_enqueued = -1;  /* batches [0, enc_enqueued] have their kernels on the stream   */
+	int64_t copy_enqueued = -1; /* the batch whose copy is on the copy stream (-1: none)        */
+	size_t copy_bytes = 0;      /* bytes of it that the enqueued copy covers                    */
+	/* shells: the alignment runs block by block, one to two blocks ahead of the encoder */
+	bool shells = false;
+	std::vector<hipEvent_t> block_start, block_done;
+	int32_t blocks_launched = 0;
+	int64_t next_batch = 0;
 	double encode_ms = 0, copy_ms = 0;
 	uint64_t raw_bytes = 0, out_bytes = 0, late_bytes = 0;
 };
@@ -509,21 +532,28 @@ static void zjob_free(sa_zjob *z)
 	if (!z)
 		return;
 	(void)hipSetDevice(z->device);
-	if (z->stream) {
-		(void)hipStreamSynchronize(z->stream);
-		(void)hipStreamDestroy(z->stream);
-	}
+	for (hipStream_t st : { z->copy_stream, z->stream })
+		if (st) {
+			(void)hipStreamSynchronize(st);
+			(void)hipStreamDestroy(st);
+		}
+	for (hipEvent_t e : z->block_start)
+		(void)hipEventDestroy(e);
+	for (hipEvent_t e : z->block_done)
+		(void)hipEventDestroy(e);
 	(void)hipFree(z->d_slots);
 	(void)hipFree(z->d_seg);
 	(void)hipFree(z->d_ghist);
 	(void)hipFree(z->d_tile_adler);
 	(void)hipFree(z->d_groups);
-	if (z->d_raw != reinterpret_cast<uint32_t *>(z->d_out))
+	if (!z->stored)
 		(void)hipFree(z->d_raw);
-	(void)hipFree(z->d_out);
-	(void)hipFree(z->d_info);
 	(void)hipFree(z->d_owned);
 	for (int k = 0; k < 2; k++) {
+		(void)hipFree(z->d_out[k]);
+		(void)hipFree(z->d_info[k]);
+		if (z->enc_done[k])
+			(void)hipEventDestroy(z->enc_done[k]);
 		if (z->h_info[k])
 			(void)hipHostFree(z->h_info[k]);
 		if (z->h_buf[k])
@@ -534,7 +564,24 @@ static void zjob_free(sa_zjob *z)
 	delete z;
 }
 
-static SaZArgs zjob_args(const sa_zjob *z, int64_t row)
+static SaZBatch zjob_batch(const sa_zjob *z, int64_t id)
+{
+	SaZBatch b;
+	if (!z->shells) { /* tile row `id` */
+		b.r0 = (int32_t)id, b.dc = 1, b.nt = z->nc;
+		return b;
+	}
+	const int32_t blk = (int32_t)((id + 1) / 2);
+	b.block = blk;
+	if (id == 0 || (id & 1)) /* the row arm, diagonal tile included */
+		b.r0 = blk, b.dc = 1, b.nt = blk + 1;
+	else                     /* the column arm */
+		b.c0 = blk, b.dr = 1, b.nt = blk;
+	return b;
+}
+static int64_t zjob_batches(const sa_zjob *z) { return z->shells ? 2 * (int64_t)z->nc - 1 : (int64_t)z->nc; }
+
+static SaZArgs zjob_args(const sa_zjob *z, const SaZBatch &b, int par)
 {
 	const size_t segs = (size_t)z->nc * (size_t)z->nseg;
 	SaZArgs a{};
@@ -543,8 +590,7 @@ static SaZArgs zjob_args(const sa_zjob *z, int64_t row)
 	a.num = z->num;
 	a.chunk = z->chunk;
 	a.chunk_shift = z->chunk_shift;
-	a.tile_row = (int32_t)row;
-	a.tile_col0 = 0;
+	a.tile_r0 = b.r0, a.tile_c0 = b.c0, a.tile_dr = b.dr, a.tile_dc = b.dc;
 	a.nseg = z->nseg;
 	a.ngrp = z->ngrp;
 	a.slots = z->d_slots;
@@ -554,11 +600,11 @@ static SaZArgs zjob_args(const sa_zjob *z, int64_t row)
 	a.seg_off = z->d_seg ? z->d_seg + 3 * segs : nullptr;
 	a.ghist = z->d_ghist;
 	a.groups = z->d_groups;
-	a.tile_bytes = z->d_info;
-	a.tile_base = z->d_info ? z->d_info + z->nc : nullptr;
+	a.tile_bytes = z->d_info[par];
+	a.tile_base = z->d_info[par] ? z->d_info[par] + z->nc : nullptr;
 	a.tile_adler = z->d_tile_adler;
-	a.out = z->d_out;
-	a.raw = z->d_raw;
+	a.out = z->d_out[par];
+	a.raw = z->stored ? reinterpret_cast<uint32_t *>(z->d_out[par]) : z->d_raw;
 	return a;
 }
 
@@ -570,43 +616,87 @@ static bool zjob_host_buffer(sa_zjob *z, int which, size_t bytes)
 		(void)hipHostFree(z->h_buf[which]);
 	z->h_buf[which] = nullptr;
 	z->h_cap[which] = 0;
-	const size_t want = std::min(z->row_bound, bytes + bytes / 16 + (1 << 20));
+	/* Page-locking is the expensive part (~0.1-0.2 ms per MB): a buffer is made once, for the largest batch to come -- nc tiles at
+	 * the bytes per tile seen so far plus a tenth (z->host_estimate; batches grow along a walk in shells: growing the buffer with
+	 * them locked 10 GB in all for config 5's 0.5 GB batches, 2 s of system time) -- and only a surprise makes it again. */
+	const size_t want = std::min(z->row_bound, std::max(bytes + bytes / 16 + (1 << 20), z->host_estimate));
 	SA_HIP_CHECK(hipHostMalloc(&z->h_buf[which], want, hipHostMallocDefault), return false);
 	z->h_cap[which] = want;
 	return true;
 }
 
-/* Everything of a tile row onto the job's stream: encode (or tile), sizes, and a copy of the first `copy_bytes` of the
- * row's compact buffer into host buffer `which` (0: the caller copies when it knows the length). */
-static bool zjob_launch(sa_zjob *z, int64_t row, int which, size_t copy_bytes)
+/* the alignment of column block `blk` (columns [blk * chunk, (blk + 1) * chunk)): one packed range, onto the stream */
+static bool zjob_align_block(sa_zjob *z, int32_t blk)
 {
-	const SaZArgs a = zjob_args(z, row);
-	const dim3 per_seg((unsigned)z->nseg, (unsigned)z->nc), per_grp((unsigned)z->ngrp, (unsigned)z->nc);
-	hipLaunchKernelGGL(sa_k_tiles_raw, dim3((unsigned)z->chunk / 64, (unsigned)z->chunk / 64, (unsigned)z->nc), dim3(ZT), 0, z->stream, a);
+	const int64_t ja = (int64_t)blk * z->chunk, jb = std::min<int64_t>((int64_t)z->num, ja + z->chunk);
+	const int64_t start = ja * (ja - 1) / 2, end = jb * (jb - 1) / 2;
+	const auto t0 = std::chrono::steady_clock::now();
+	SA_HIP_CHECK(hipEventRecord(z->block_start[(size_t)blk], z->stream), return false);
+	if (end > start && sa_ctx_align_range(z->ctx, start, end - start, z->d_owned + start, z->stream) != 0)
+		return false;
+	SA_HIP_CHECK(hipEventRecord(z->block_done[(size_t)blk], z->stream), return false);
+	if (getenv("SA_HIP_ZTRACE"))
+		fprintf(stderr, "[zjob] block %d: %lld pairs launched in %.2f ms of host time\n", blk, (long long)(end - start), sa_ms_since(t0));
+	return true;
+}
+static bool zjob_align_upto(sa_zjob *z, int32_t blk)
+{
+	while (z->blocks_launched < z->nc && z->blocks_launched <= blk) {
+		if (!zjob_align_block(z, z->blocks_launched))
+			return false;
+		z->blocks_launched++;
+	}
+	return true;
+}
+
+/* the kernels of batch `id` onto the stream (raw tiles, encoding, sizes into d_info[id & 1], streams into d_out[id & 1]); the
+ * caller has seen batch id - 2 arrive, so both are free */
+static bool zjob_enqueue_encode(sa_zjob *z, int64_t id)
+{
+	const SaZBatch b = zjob_batch(z, id);
+	const int par = (int)(id & 1);
+	if (b.block >= 0 && !zjob_align_upto(z, b.block)) /* (in order: the batch's column block is on the stream before it) */
+		return false;
+	const SaZArgs a = zjob_args(z, b, par);
+	const unsigned nt = (unsigned)b.nt;
+	const dim3 per_seg((unsigned)z->nseg, nt), per_grp((unsigned)z->ngrp, nt);
+	hipLaunchKernelGGL(sa_k_tiles_raw, dim3((unsigned)z->chunk / 64, (unsigned)z->chunk / 64, nt), dim3(ZT), 0, z->stream, a);
 	SA_HIP_CHECK(hipGetLastError(), return false);
 	if (!z->stored) {
-		SA_HIP_CHECK(hipMemsetAsync(z->d_ghist, 0, sizeof(uint32_t) * (size_t)z->nc * (size_t)z->ngrp * ZHIST, z->stream), return false);
+		SA_HIP_CHECK(hipMemsetAsync(z->d_ghist, 0, sizeof(uint32_t) * (size_t)nt * (size_t)z->ngrp * ZHIST, z->stream), return false);
 		hipLaunchKernelGGL(sa_k_deflate_hist, per_seg, dim3(ZT), 0, z->stream, a);
 		SA_HIP_CHECK(hipGetLastError(), return false);
 		hipLaunchKernelGGL(sa_k_deflate_codes, per_grp, dim3(ZT), 0, z->stream, a);
 		SA_HIP_CHECK(hipGetLastError(), return false);
 		hipLaunchKernelGGL(sa_k_deflate_encode, per_seg, dim3(ZT), 0, z->stream, a);
 		SA_HIP_CHECK(hipGetLastError(), return false);
-		hipLaunchKernelGGL(sa_k_deflate_offsets, dim3((unsigned)z->nc), dim3(ZT), 0, z->stream, a);
+		hipLaunchKernelGGL(sa_k_deflate_offsets, dim3(nt), dim3(ZT), 0, z->stream, a);
 		SA_HIP_CHECK(hipGetLastError(), return false);
-		hipLaunchKernelGGL(sa_k_deflate_rowbase, dim3(1), dim3(64), 0, z->stream, a, (int)z->nc);
+		hipLaunchKernelGGL(sa_k_deflate_rowbase, dim3(1), dim3(64), 0, z->stream, a, (int)nt);
 		SA_HIP_CHECK(hipGetLastError(), return false);
 		hipLaunchKernelGGL(sa_k_deflate_gather, per_seg, dim3(ZT), 0, z->stream, a);
 		SA_HIP_CHECK(hipGetLastError(), return false);
-		SA_HIP_CHECK(hipMemcpyAsync(z->h_info[which], z->d_info, sizeof(unsigned long long) * (size_t)(2 * z->nc + 1), hipMemcpyDeviceToHost,
-					    z->stream),
+	}
+	SA_HIP_CHECK(hipEventRecord(z->enc_done[par], z->stream), return false);
+	z->enc_enqueued = id;
+	return true;
+}
+
+/* the copy of batch `id` onto the copy stream: sizes, and the first `bytes` of its compact buffer into host buffer `which` */
+static bool zjob_enqueue_copy(sa_zjob *z, int64_t id, int which, size_t bytes)
+{
+	const int par = (int)(id & 1);
+	SA_HIP_CHECK(hipStreamWaitEvent(z->copy_stream, z->enc_done[par], 0), return false);
+	if (!z->stored) {
+		SA_HIP_CHECK(hipMemcpyAsync(z->h_info[par], z->d_info[par], sizeof(unsigned long long) * (size_t)(2 * z->nc + 1), hipMemcpyDeviceToHost,
+					    z->copy_stream),
 			     return false);
 	}
-	if (copy_bytes) {
-		SA_HIP_CHECK(hipMemcpyAsync(z->h_buf[which], z->d_out, copy_bytes, hipMemcpyDeviceToHost, z->stream), return false);
+	if (bytes) {
+		SA_HIP_CHECK(hipMemcpyAsync(z->h_buf[which], z->d_out[par], bytes, hipMemcpyDeviceToHost, z->copy_stream), return false);
 	}
-	z->launched_row = row;
-	z->launched_copy = copy_bytes;
+	z->copy_enqueued = id;
+	z->copy_bytes = bytes;
 	return true;
 }
 
@@ -641,16 +731,30 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 	/* a tile's stream at its very worst (header, 63 bits per element, the segments' ends), on a 64-byte boundary */
 	z->tile_bound = stored ? chunk_dim * chunk_dim * sizeof(int32_t) : (((size_t)z->nseg * ZSLOT_WORDS * 4 + 64) + 255) & ~(size_t)255;
 	z->row_bound = (size_t)z->nc * z->tile_bound;
-	/* a second host buffer lets row r + 1 be copied while the caller writes row r; page-locking it costs ~0.1-0.2 ms per MB,
+	/* a second host buffer lets batch k + 1 be copied while the caller writes batch k; page-locking it costs ~0.1-0.2 ms per MB,
 	 * the copies it hides ~0.02 ms per MB and row: worth it from eight tile rows on -- for streams.  Raw tiles are three
 	 * times the bytes per row: config 4 (13 rows of 872 MB) measured 1.50 s with one buffer, 1.83 s with two. */
 	z->two_buffers = !stored && z->nc >= 8;
+	if (stored)
+		z->host_estimate = z->row_bound;
 	bool ok = false;
 	do {
 		SA_HIP_CHECK(hipStreamCreateWithFlags(&z->stream, hipStreamNonBlocking), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_out, z->row_bound), break);
+		SA_HIP_CHECK(hipStreamCreateWithFlags(&z->copy_stream, hipStreamNonBlocking), break);
+		bool both = true;
+		for (int k = 0; k < 2 && both; k++) {
+			both = false;
+			SA_HIP_CHECK(hipEventCreateWithFlags(&z->enc_done[k], hipEventDisableTiming), break);
+			SA_HIP_CHECK(hipMalloc(&z->d_out[k], z->row_bound), break);
+			if (!stored) {
+				SA_HIP_CHECK(hipMalloc(&z->d_info[k], sizeof(unsigned long long) * (size_t)(2 * z->nc + 1)), break);
+				SA_HIP_CHECK(hipHostMalloc(&z->h_info[k], sizeof(unsigned long long) * (size_t)(2 * z->nc + 1), hipHostMallocDefault), break);
+			}
+			both = true;
+		}
+		if (!both)
+			break;
 		if (stored) {
-			z->d_raw = reinterpret_cast<uint32_t *>(z->d_out);
 			ok = true;
 			break;
 		}
@@ -660,11 +764,6 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 		SA_HIP_CHECK(hipMalloc(&z->d_ghist, sizeof(uint32_t) * (size_t)z->nc * (size_t)z->ngrp * ZHIST), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_groups, sizeof(SaZGroup) * (size_t)z->nc * (size_t)z->ngrp), break);
 		SA_HIP_CHECK(hipMalloc(&z->d_tile_adler, sizeof(uint32_t) * (size_t)z->nc), break);
-		SA_HIP_CHECK(hipMalloc(&z->d_info, sizeof(unsigned long long) * (size_t)(2 * z->nc + 1)), break);
-		for (int k = 0; k < 2; k++)
-			SA_HIP_CHECK(hipHostMalloc(&z->h_info[k], sizeof(unsigned long long) * (size_t)(2 * z->nc + 1), hipHostMallocDefault), break);
-		if (!z->h_info[0] || !z->h_info[1])
-			break;
 		ok = true;
 	} while (0);
 	if (!ok) {
@@ -672,6 +771,109 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 		return nullptr;
 	}
 	return z;
+}
+
+/* The tiles of batch `id` into page-locked memory: tile t at streams[t], sizes[t] bytes.  Returns their number, < 0 on error.
+ * Before it returns, the kernels of the batches that follow -- in shells: both arms of the next column block, then the
+ * alignment of the block after it -- and (two host buffers) the next batch's copy are enqueued: they run while the caller
+ * writes this batch. */
+static int zjob_fetch(sa_zjob *z, int64_t id, const uint8_t **streams, size_t *sizes)
+{
+	SA_HIP_CHECK(hipSetDevice(z->device), return -1);
+	const SaZBatch b = zjob_batch(z, id);
+	const int par = (int)(id & 1), which = z->two_buffers ? par : 0;
+	const size_t raw_row = (size_t)b.nt * z->tile_bound;
+	const auto t0 = std::chrono::steady_clock::now();
+	if (id > z->enc_enqueued) { /* (the first batch; batches are handed out in order) */
+		if (id != z->enc_enqueued + 1) {
+			sa_set_error("sa_zjob: batches are handed out in order");
+			return -1;
+		}
+		if (!zjob_enqueue_encode(z, id))
+			return -1;
+	} else if (id < z->enc_enqueued - 1) { /* (its buffers belong to batch id + 2 by now) */
+		sa_set_error("sa_zjob: batch %lld is gone (batches are handed out in order, once)", (long long)id);
+		return -1;
+	}
+	if (z->copy_enqueued != id) {
+		size_t bytes = 0;
+		if (z->stored) {
+			bytes = raw_row;
+			if (!zjob_host_buffer(z, which, bytes))
+				return -1;
+		}
+		if (!zjob_enqueue_copy(z, id, which, bytes))
+			return -1;
+	}
+	SA_HIP_CHECK(hipStreamSynchronize(z->copy_stream), return -1);
+	z->encode_ms += sa_ms_since(t0);
+	const auto t1 = std::chrono::steady_clock::now();
+	size_t total = raw_row;
+	if (!z->stored) {
+		const unsigned long long *info = z->h_info[par];
+		total = (size_t)info[z->nc + b.nt];
+		if (total > z->row_bound) {
+			sa_set_error("sa_zjob: a batch of tiles outgrew its bound (%zu > %zu)", total, z->row_bound);
+			return -1;
+		}
+		if (!z->host_estimate)
+			z->host_estimate = (size_t)((double)total / (double)b.nt * (double)z->nc * 1.1) + (1 << 20);
+		if (total > z->copy_bytes) { /* what the enqueued copy did not cover (the first batch: everything) */
+			size_t have = z->copy_bytes;
+			if (total > z->h_cap[which]) { /* (a new buffer: the part already copied is copied again) */
+				if (!zjob_host_buffer(z, which, total))
+					return -1;
+				have = 0;
+			}
+			SA_HIP_CHECK(hipMemcpyAsync(z->h_buf[which] + have, z->d_out[par] + have, total - have, hipMemcpyDeviceToHost, z->copy_stream),
+				     return -1);
+			SA_HIP_CHECK(hipStreamSynchronize(z->copy_stream), return -1);
+			z->late_bytes += total - have;
+		}
+		for (int t = 0; t < b.nt; t++) {
+			sizes[t] = (size_t)info[t];
+			streams[t] = z->h_buf[which] + (size_t)info[z->nc + t];
+			z->out_bytes += sizes[t];
+		}
+	} else {
+		for (int t = 0; t < b.nt; t++) {
+			sizes[t] = z->tile_bound;
+			streams[t] = z->h_buf[which] + (size_t)t * z->tile_bound;
+			z->out_bytes += sizes[t];
+		}
+	}
+	z->raw_bytes += (uint64_t)b.nt * (uint64_t)z->chunk * (uint64_t)z->chunk * 4u;
+	z->copy_ms += sa_ms_since(t1);
+	z->copy_enqueued = -1;
+	if (getenv("SA_HIP_ZTRACE"))
+		fprintf(stderr, "[zjob] batch %lld (%d tiles, block %d): waited %.2f ms, copy %.2f ms, %zu bytes\n", (long long)id, b.nt, b.block,
+			std::chrono::duration<double, std::milli>(t1 - t0).count(), sa_ms_since(t1), total);
+	/* ---- what runs while the caller writes this batch ---- */
+	const int64_t last = zjob_batches(z) - 1;
+	if (id < last) {
+		if (z->enc_enqueued == id) { /* nothing ahead: the kernels of the next batch -- in shells of the next BLOCK: both arms -- and
+					       * then the alignment of one more block, so that the stream never runs dry while the host writes */
+			if (!zjob_enqueue_encode(z, id + 1))
+				return -1;
+			if (z->shells) {
+				const SaZBatch nb = zjob_batch(z, id + 1);
+				if (id + 2 <= last && zjob_batch(z, id + 2).block == nb.block && !zjob_enqueue_encode(z, id + 2))
+					return -1;
+				if (!zjob_align_upto(z, nb.block + 1))
+					return -1;
+			}
+		}
+		if (z->two_buffers) { /* (one host buffer: a copy would overwrite what the caller is about to read) */
+			const SaZBatch nb = zjob_batch(z, id + 1);
+			const int next = (int)((id + 1) & 1);
+			/* (the length is not known yet: this batch's bytes per tile, plus 3 %) */
+			const size_t guess = (size_t)((double)total / (double)b.nt * (double)nb.nt * 1.03) + (1 << 16);
+			const size_t bytes = std::min((size_t)nb.nt * z->tile_bound, guess);
+			if (!zjob_host_buffer(z, next, bytes) || !zjob_enqueue_copy(z, id + 1, next, bytes))
+				return -1;
+		}
+	}
+	return b.nt;
 }
 
 extern "C" sa_zjob *sa_zjob_create(int device, const int32_t *d_packed, const int32_t *d_full, int32_t num, size_t chunk_dim, int level)
@@ -689,79 +891,33 @@ extern "C" size_t sa_zjob_tiles_per_row(const sa_zjob *job) { return job ? (size
 extern "C" int sa_zjob_tile_row(sa_zjob *z, size_t tile_row, const uint8_t **streams, size_t *sizes)
 {
 	return sa_guard("sa_zjob_tile_row", 1, [&]() -> int {
-		if (!z || !streams || !sizes || tile_row >= (size_t)z->nc) {
+		if (!z || !streams || !sizes || tile_row >= (size_t)z->nc || z->shells) {
 			sa_set_error("sa_zjob_tile_row: bad arguments");
 			return 1;
 		}
-		SA_HIP_CHECK(hipSetDevice(z->device), return 1);
-		const int which = z->two_buffers ? (int)(tile_row & 1) : 0;
-		const auto t0 = std::chrono::steady_clock::now();
-		if (z->launched_row != (int64_t)tile_row) { /* the first row, or rows asked for out of order: nothing is on its way */
-			size_t copy = 0;
-			if (z->stored) {
-				copy = z->row_bound;
-				if (!zjob_host_buffer(z, which, copy))
-					return 1;
-			}
-			if (!zjob_launch(z, (int64_t)tile_row, which, copy))
-				return 1;
+		return zjob_fetch(z, (int64_t)tile_row, streams, sizes) < 0 ? 1 : 0;
+	});
+}
+
+extern "C" int sa_zjob_next(sa_zjob *z, uint32_t *rows, uint32_t *cols, const uint8_t **streams, size_t *sizes)
+{
+	return sa_guard("sa_zjob_next", -1, [&]() -> int {
+		if (!z || !rows || !cols || !streams || !sizes) {
+			sa_set_error("sa_zjob_next: bad arguments");
+			return -1;
 		}
-		SA_HIP_CHECK(hipStreamSynchronize(z->stream), return 1);
-		z->encode_ms += sa_ms_since(t0);
-		const auto t1 = std::chrono::steady_clock::now();
-		size_t total = z->row_bound;
-		if (!z->stored) {
-			const unsigned long long *info = z->h_info[which];
-			total = (size_t)info[2 * z->nc];
-			if (total > z->row_bound) {
-				sa_set_error("sa_zjob_tile_row: a tile row outgrew its bound (%zu > %zu)", total, z->row_bound);
-				return 1;
-			}
-			if (total > z->launched_copy) { /* what the enqueued copy did not cover (the first row: everything) */
-				size_t have = z->launched_copy;
-				if (total > z->h_cap[which]) { /* (a new buffer: the part already copied is copied again) */
-					if (!zjob_host_buffer(z, which, total))
-						return 1;
-					have = 0;
-				}
-				SA_HIP_CHECK(hipMemcpyAsync(z->h_buf[which] + have, z->d_out + have, total - have, hipMemcpyDeviceToHost, z->stream), return 1);
-				SA_HIP_CHECK(hipStreamSynchronize(z->stream), return 1);
-				z->late_bytes += total - have;
-			}
-			for (int t = 0; t < z->nc; t++) {
-				sizes[t] = (size_t)info[t];
-				streams[t] = z->h_buf[which] + (size_t)info[z->nc + t];
-				z->out_bytes += sizes[t];
-			}
-		} else {
-			for (int t = 0; t < z->nc; t++) {
-				sizes[t] = z->tile_bound;
-				streams[t] = z->h_buf[which] + (size_t)t * z->tile_bound;
-				z->out_bytes += sizes[t];
-			}
+		if (z->next_batch >= zjob_batches(z))
+			return 0;
+		const SaZBatch b = zjob_batch(z, z->next_batch);
+		const int n = zjob_fetch(z, z->next_batch, streams, sizes);
+		if (n < 0)
+			return -1;
+		for (int t = 0; t < n; t++) {
+			rows[t] = (uint32_t)(b.r0 + t * b.dr);
+			cols[t] = (uint32_t)(b.c0 + t * b.dc);
 		}
-		z->raw_bytes += (uint64_t)z->nc * (uint64_t)z->chunk * (uint64_t)z->chunk * 4u;
-		z->last_total = total;
-		z->copy_ms += sa_ms_since(t1);
-		/* the next row is encoded and copied while the caller writes this one.  With one host buffer the copy would
-		 * overwrite what the caller is about to read: then only the encoding runs ahead. */
-		if (tile_row + 1 < (size_t)z->nc) {
-			const int next = z->two_buffers ? (int)((tile_row + 1) & 1) : 0;
-			size_t copy = 0;
-			if (z->two_buffers) {
-				copy = z->stored ? z->row_bound : std::min(z->row_bound, total + total / 32 + (1 << 16));
-				if (!zjob_host_buffer(z, next, copy))
-					return 1;
-			}
-			if (!z->two_buffers && z->stored) {
-				/* (raw tiles, one buffer: the kernel may run ahead, the copy waits for the next call) */
-				z->launched_row = -1;
-				return 0;
-			}
-			if (!zjob_launch(z, (int64_t)tile_row + 1, next, copy))
-				return 1;
-		}
-		return 0;
+		z->next_batch++;
+		return n;
 	});
 }
 
@@ -779,10 +935,28 @@ extern "C" void sa_zjob_stats(const sa_zjob *z, double *encode_ms, double *copy_
 		*out_bytes = z->out_bytes;
 }
 
-/* the alignment into device memory (all pairs, packed) and a job over it; *align_seconds = the launch loop's time */
-extern "C" sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level, double *align_seconds)
+/* seconds the device spent aligning so far: the sum over the column blocks whose kernels have finished */
+extern "C" double sa_zjob_align_seconds(const sa_zjob *z)
 {
-	return sa_guard("sa_hip_deflate_begin", (sa_zjob *)nullptr, [&]() -> sa_zjob * {
+	return sa_guard("sa_zjob_align_seconds", 0.0, [&]() -> double {
+		if (!z || !z->shells)
+			return 0.0;
+		double ms = 0.0;
+		for (int32_t k = 0; k < z->blocks_launched; k++) {
+			float one = 0.f;
+			if (hipEventElapsedTime(&one, z->block_start[(size_t)k], z->block_done[(size_t)k]) == hipSuccess)
+				ms += one;
+		}
+		(void)hipGetLastError();
+		return ms * 1e-3;
+	});
+}
+
+/* Context + the packed matrix in device memory + a job that walks it in shells while the alignment runs (see SaZBatch): the
+ * first column blocks are on their way when this returns. */
+extern "C" sa_zjob *sa_hip_tiles_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level)
+{
+	return sa_guard("sa_hip_tiles_begin", (sa_zjob *)nullptr, [&]() -> sa_zjob * {
 		sa_ctx *ctx = sa_ctx_create(0, in, sc);
 		if (!ctx)
 			return nullptr;
@@ -792,27 +966,38 @@ extern "C" sa_zjob *sa_hip_deflate_begin(struct sa_input in, const struct sa_sco
 		do {
 			const int64_t pairs = sa_ctx_pairs(ctx);
 			SA_HIP_CHECK(hipMalloc(&d_packed, sizeof(int32_t) * (size_t)pairs), break);
-			if (!sa_prepare_range(ctx, 0, pairs, false))
-				break;
-			SA_HIP_CHECK(hipDeviceSynchronize(), break);
-			const auto t0 = std::chrono::steady_clock::now();
-			if (sa_ctx_align_range(ctx, 0, pairs, d_packed, nullptr) != 0)
-				break;
-			SA_HIP_CHECK(hipDeviceSynchronize(), break);
-			if (align_seconds)
-				*align_seconds = sa_ms_since(t0) * 1e-3;
 			z = zjob_make(0, d_packed, nullptr, in.num, chunk_dim, level == 0);
 			if (!z)
 				break;
+			z->shells = true;
+			z->block_start.assign((size_t)z->nc, nullptr);
+			z->block_done.assign((size_t)z->nc, nullptr);
+			bool ev = true;
+			for (int32_t k = 0; k < z->nc && ev; k++)
+				ev = hipEventCreate(&z->block_start[(size_t)k]) == hipSuccess && hipEventCreate(&z->block_done[(size_t)k]) == hipSuccess;
+			if (!ev) {
+				sa_set_error("sa_hip_tiles_begin: hipEventCreate failed");
+				break;
+			}
 			ok = true;
 		} while (0);
+		if (z) { /* (the job owns context and matrix from here on, whatever happens) */
+			z->d_owned = d_packed;
+			z->ctx = ctx;
+		}
+		if (ok) {
+			/* the alignment starts now: the first blocks are small, the caller's file set-up runs beside them */
+			ok = zjob_align_upto(z, 1);
+		}
 		if (!ok) {
-			(void)hipFree(d_packed);
-			sa_ctx_destroy(ctx);
+			if (z)
+				zjob_free(z);
+			else {
+				(void)hipFree(d_packed);
+				sa_ctx_destroy(ctx);
+			}
 			return nullptr;
 		}
-		z->d_owned = d_packed;
-		z->ctx = ctx;
 		return z;
 	});
 }

@@ -147,7 +147,7 @@ bool sa_plan_get(sa_ctx *ctx, int64_t start, int64_t count, int world, bool shar
 		double a0;
 		~Acc() { c->setup.plan += sa_ms_since(t) - (c->setup.arrange - a0); }
 	} acc{ ctx, t_plan, ctx->setup.arrange };
-	constexpr size_t MAX_PLANS = 32;
+	constexpr size_t MAX_PLANS = 160; /* (a walk in shells -- sa_deflate.hip -- holds one plan per column block: 74 for 300 000 sequences) */
 	ctx->plan = nullptr;
 	if (ctx->plans.size() >= MAX_PLANS) { /* evict the least recently used (hipFree waits for its users) */
 		size_t victim = 0;

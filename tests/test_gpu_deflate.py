@@ -125,3 +125,36 @@ def test_level_zero_returns_the_tiles_as_they_are(sa):
     with sa.DeflateJob(n, chunk, d_packed_ptr=d.data_ptr(), level=0) as job:
         for r in range(nc):
             assert job.tile_row(r) == want[r]
+
+
+@pytest.mark.parametrize("level", [6, 0])
+@pytest.mark.parametrize("n,chunk,method", [(2100, 512, "nw"), (1300, 256, "sw"), (300, 256, "ga")])
+def test_shells_while_the_alignment_runs(n, chunk, method, level, sa, oracle):
+    """sa_hip_tiles_begin / sa_zjob_next: the alignment runs column block by column block and the tiles come out shell by
+    shell (those whose larger tile index is b need exactly block b) -- every tile exactly once, each the bytes of the oracle's
+    matrix (zero diagonal, zero padding), deflated or raw."""
+    from tests.synth import make_protein_set
+    store = sa.SequenceStore.from_sequences(make_protein_set(n, 20, 90, n))
+    gaps = dict(gap_pen=4) if method == "nw" else dict(gap_open=10, gap_extend=1)
+    scoring = sa.Scoring.from_names(method, "blosum62", **gaps)
+    full = tri_to_full(oracle.align(store, scoring, triangular=True), n)
+    nc, want = expected_tiles(full, chunk)
+    seen = {}
+    with sa.DeflateJob.begin(store, scoring, chunk, level=level) as job:
+        assert job.tiles_per_row == nc
+        order = []
+        while True:
+            batch = job.next()
+            if not batch:
+                break
+            assert len(batch) <= nc
+            for r, c, z in batch:
+                assert (r, c) not in seen
+                seen[(r, c)] = zlib.decompress(z) if level else z
+                order.append(max(r, c))
+        assert job.next() == []
+        assert order == sorted(order)  # shell after shell
+        assert job.align_seconds > 0
+    assert len(seen) == nc * nc
+    for (r, c), got in seen.items():
+        assert got == want[r][c], (r, c)
