@@ -270,6 +270,24 @@ static void progress_line(double fraction, void *user)
 	fflush(stderr);
 }
 
+/* the tiles of the device walk as they arrive (sa_zjob_next), with the progress line fed from them: tile (r, c) of shell
+ * b = max(r, c) arrives when column block b is aligned, and the pairs up to there are (b + 1)^2 of nc^2 */
+struct tile_feed {
+	sa_zjob *job;
+	size_t nc;
+	bool show;
+};
+static int next_tiles(void *user, uint32_t *rows, uint32_t *cols, const uint8_t **streams, size_t *sizes)
+{
+	struct tile_feed *f = user;
+	const int n = sa_zjob_next(f->job, rows, cols, streams, sizes);
+	if (n > 0 && f->show) {
+		const uint32_t b = rows[n - 1] > cols[n - 1] ? rows[n - 1] : cols[n - 1];
+		progress_line((double)(b + 1) * (double)(b + 1) / ((double)f->nc * (double)f->nc), NULL);
+	}
+	return n;
+}
+
 int main(int argc, char **argv)
 {
 	t_process0 = now();
@@ -397,7 +415,7 @@ int main(int argc, char **argv)
 	struct sa_output out = { NULL, NULL, n, false };
 	bool pinned = false;
 	/* -z on a chunked dataset: the tiles are deflated on the device, from the packed scores where they were computed
-	 * (include/seqalign_hip.h: sa_hip_deflate_begin / sa_zjob_tile_row) -- no host matrix at all.  libhdf5's filter in the
+	 * (include/seqalign_hip.h: sa_hip_tiles_begin / sa_zjob_next) -- no host matrix at all.  libhdf5's filter in the
 	 * one writing thread (what flush_hdf5 leaves to H5Dwrite, src/io/format/hdf5.c:148-194) takes 41 CPU-minutes for config 5.
 	 * SA_HOST_CPU_DEFLATE=1 keeps zlib at exactly the level asked for (all cores, sa_host_write_hdf5). */
 	const long long npairs = (long long)n * ((long long)n - 1) / 2;
@@ -468,7 +486,8 @@ int main(int argc, char **argv)
 		t_setup = now() - t0;
 		stamp("sa_hip_tiles_begin returned");
 		t0 = now();
-		if (sa_host_write_hdf5_streams(o.output, &store, o.compression, (sa_host_tiles_fn)sa_zjob_next, job)) {
+		struct tile_feed feed = { job, sa_zjob_tiles_per_row(job), show_progress };
+		if (sa_host_write_hdf5_streams(o.output, &store, o.compression, next_tiles, &feed)) {
 			err("%s (%s)", sa_host_error(), sa_last_error());
 			return 1;
 		}

@@ -26,9 +26,10 @@
  *   sa_k_deflate_rowbase  where each tile goes in the row's compact buffer.
  *   sa_k_deflate_gather   one workgroup per segment: its bytes to their place (dword copies with a funnel shift
  *                         between the byte alignment of slot and stream); the first one adds the tile's header and end.
- * Host: a job walks the tile rows; row r + 1 is encoded AND copied to the host while the caller hands row r to
- * H5Dwrite_chunk (the copy's length is not known when it is enqueued: it takes the previous row's length plus 3 %,
- * and what that misses -- normally nothing -- follows when the sizes are there).
+ * Host: a job hands out batches of tiles -- tile rows over a finished matrix, or, while the alignment is still running, the
+ * arms of SHELLS (see SaZBatch); the next batches are encoded and copied while the caller hands this one to H5Dwrite_chunk
+ * (the copy's length is not known when it is enqueued: it takes this batch's bytes per tile plus 3 %, and what that
+ * misses -- normally nothing -- follows when the sizes are there).
  */
 #include <algorithm>
 #include <chrono>
