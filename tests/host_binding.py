@@ -41,6 +41,8 @@ class Host:
         lib.sa_host_filter.restype = C.c_int32
         lib.sa_host_store_free.argtypes = [C.POINTER(_Store)]
         lib.sa_host_write_hdf5.argtypes = [C.c_char_p, C.POINTER(_Store), C.c_void_p, C.c_bool, C.c_uint]
+        self.TILES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t))
+        lib.sa_host_write_hdf5_streams.argtypes = [C.c_char_p, C.POINTER(_Store), C.c_uint, self.TILES_FN, C.c_void_p]
         lib.sa_host_hdf5_chunk_dim.argtypes = [C.c_size_t]
         lib.sa_host_hdf5_chunk_dim.restype = C.c_size_t
         self.lib = lib
@@ -94,6 +96,30 @@ class Host:
         try:
             m = np.ascontiguousarray(matrix, np.int32).reshape(-1)
             if self.lib.sa_host_write_hdf5(str(path).encode(), C.byref(st), m.ctypes.data, bool(triangular), compression):
+                raise HostError(self._err())
+        finally:
+            self.lib.sa_host_store_free(C.byref(st))
+
+    def write_hdf5_streams(self, path, seqs: list[bytes], lut: np.ndarray, compression: int, batches):
+        """sa_host_write_hdf5_streams with `batches` (an iterable of lists of (tile row, tile column, bytes)) as the tile source --
+        what sa_zjob_next is for the tool; a batch of None makes the source report an error"""
+        data = b"".join(b">s\n" + s + b"\n" for s in seqs)
+        st = self.parse(data, "fasta", lut)
+        it = iter(batches)
+        keep = []
+
+        def source(user, rows, cols, streams, sizes):
+            batch = next(it, [])
+            if batch is None:
+                return -1
+            keep.clear()
+            for t, (r, c, z) in enumerate(batch):
+                buf = C.create_string_buffer(z, len(z))
+                keep.append(buf)
+                rows[t], cols[t], streams[t], sizes[t] = r, c, C.addressof(buf), len(z)
+            return len(batch)
+        try:
+            if self.lib.sa_host_write_hdf5_streams(str(path).encode(), C.byref(st), compression, self.TILES_FN(source), None):
                 raise HostError(self._err())
         finally:
             self.lib.sa_host_store_free(C.byref(st))

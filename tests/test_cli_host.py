@@ -238,3 +238,45 @@ def test_hdf5_writer_under_sanitizers(tmp_path):
         diff = subprocess.run([str(H5DIFF), str(a), str(b)], capture_output=True, text=True)
         assert diff.returncode == 0, diff.stdout + diff.stderr
         a.unlink(), b.unlink()
+
+
+@pytest.mark.parametrize("z", [6, 0])
+def test_hdf5_from_finished_tiles(host, tmp_path, amino_lut, z):
+    """sa_host_write_hdf5_streams: the tiles arrive finished (zlib streams for -z, raw tiles without) in batches of at most
+    ceil(N / chunk) tiles, in ANY order -- here in the shell order of the device walk (include/seqalign_hip.h: sa_zjob_next) --
+    and go to H5Dwrite_chunk as they are; the file reads back through libhdf5 as the matrix, with the dataset layout of
+    sa_host_write_hdf5.  A source that reports an error, or delivers too few tiles, fails the call."""
+    import zlib
+    n = 700
+    rng = np.random.default_rng(11)
+    tri = rng.integers(-300, 200, n * (n - 1) // 2, dtype=np.int32)
+    want = tri_to_full(tri, n)
+    seqs = [bytes(rng.choice(list(b"ARNDCQEG"), 4).astype(np.uint8)) for _ in range(n)]
+    chunk = host.chunk_dim(n)
+    nc = -(-n // chunk)
+    pad = np.zeros((nc * chunk, nc * chunk), np.int32)
+    pad[:n, :n] = want
+
+    def tile(r, c):
+        raw = pad[r * chunk:(r + 1) * chunk, c * chunk:(c + 1) * chunk].astype("<i4").tobytes()
+        return (r, c, zlib.compress(raw, 1) if z else raw)
+    shells = []
+    for b in range(nc):
+        shells.append([tile(b, c) for c in range(b + 1)])
+        if b:
+            shells.append([tile(r, b) for r in range(b)])
+    path = tmp_path / "tiles.h5"
+    host.write_hdf5_streams(path, seqs, amino_lut, z, shells)
+    assert np.array_equal(h5_matrix(path, n), want)
+    assert h5_sequences(path) == seqs
+    hdr = subprocess.run([str(H5DUMP), "-H", "-p", str(path)], capture_output=True, text=True).stdout
+    assert f"CHUNKED ( {chunk}, {chunk} )" in hdr and ("DEFLATE { LEVEL 6 }" in hdr) == bool(z)
+    ref = tmp_path / "ref.h5"
+    host.write_hdf5(ref, seqs, amino_lut, tri, True, z)
+    assert subprocess.run([str(H5DIFF), str(path), str(ref)], capture_output=True).returncode == 0
+    with pytest.raises(HostError, match="tiles"):
+        host.write_hdf5_streams(tmp_path / "short.h5", seqs, amino_lut, z, shells[:-1])
+    with pytest.raises(HostError, match="encode"):
+        host.write_hdf5_streams(tmp_path / "bad.h5", seqs, amino_lut, z, shells[:1] + [None])
+    with pytest.raises(HostError, match="chunked"):
+        host.write_hdf5_streams(tmp_path / "small.h5", seqs[:100], amino_lut, z, [])
