@@ -260,8 +260,9 @@ def cli_leg(seqs, cfg, quiet: bool = True) -> dict | None:
             "alignments_per_second": grab("Alignments per second"), "input_s": grab("Input"), "filter_s": grab("Filter"),
             "alignment_s": grab("Alignment"), "output_s": grab("Output"), "setup_s": grab(r"outside the phases as in the reference"),
             "process_wall_s": wall,
-            "note": "cold process, FASTA -> full N x N HDF5; alignment = the launch/copy loop (reference's bench_align bracket), "
-                    "setup = context, code-object load, upload, buffers and page-locking (outside the phases as in the reference)"}
+            "note": "cold process, FASTA -> full N x N HDF5, the chunks tiled on the device and written while the next column blocks are "
+                    "aligned (DESIGN.md 4.8); alignment = the device's alignment time (reference's bench_align bracket), output = the "
+                    "rest of that section, setup = context, code-object load, upload, buffers (outside the phases as in the reference)"}
 
 
 def extra_config(name: str, n, steps: int, cpu_seconds: float, cpu_full_seconds: float, torch, sa, make_config) -> dict:
