@@ -69,3 +69,71 @@ def test_full_size_host_delivered_columns_match_the_reference(name, sa):
             assert any(tri(j) < (1 << 31) <= tri(j + 1) for j in cols)
     finally:
         dest.close()
+
+
+@pytest.mark.parametrize("name", ["cfg4", "cfg5"])
+def test_full_size_tool_output_matches_the_reference(name, tmp_path):
+    """the same fixtures through the PRODUCT: cli/seqalign on the whole config -- cfg 5 with its options `-f 0.9 -z 6` -- writes
+    the N x N HDF5 file (device filter, alignment column block by column block, the tiles of every shell deflated / tiled on the
+    device and written meanwhile: DESIGN.md 4.8), and the pinned columns are read back out of that file through libhdf5
+    (h5dump: its inflate for cfg 5) -- column j of the packed matrix is row j of the file up to the diagonal."""
+    import os
+    import subprocess
+    from tests.host_binding import H5DUMP, ROOT
+    z = np.load(GOLDEN / f"stripes_{name}.npz")
+    meta = json.loads(str(z["params"]))
+    seqs, cfg = make_config(name)
+    scratch = pathlib.Path(os.environ.get("SA_TEST_SCRATCH", "/tmp")) / f"sa_tool_{name}_{os.getpid()}"
+    scratch.mkdir(parents=True, exist_ok=True)
+    fasta, out = scratch / "in.fasta", scratch / "out.h5"
+    try:
+        fasta.write_bytes(b"".join(b">s%d\n" % k + s + b"\n" for k, s in enumerate(seqs)))
+        gaps = cfg["gaps"]
+        flags = ["-p", gaps["gap_pen"]] if "gap_pen" in gaps else ["-s", gaps["gap_open"], "-e", gaps["gap_extend"]]
+        if name == "cfg5":
+            flags += ["-f", "0.9", "-z", "6"]
+        res = subprocess.run([str(ROOT / "cli" / "seqalign"), "-i", str(fasta), "-o", str(out), "-a", cfg["method"], "-m", cfg["matrix"],
+                              *map(str, flags), "-B", "-F", "-Q"], capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stdout + res.stderr
+        assert "tiles" in res.stdout and "on the device" in res.stdout or "delivered as HDF5 chunks" in res.stdout, res.stdout
+        n = meta["n"]
+        cols = z["cols"].tolist()
+        # the stored chunks of the tile rows that hold the pinned columns (tests/host_c/chunk_read.c: H5Dread_chunk), inflated here
+        reader = scratch / "chunk_read"
+        subprocess.check_call(["gcc", "-std=c11", "-O2", "-I/opt/conda/include", str(ROOT / "tests" / "host_c" / "chunk_read.c"), "-o", str(reader),
+                               "-L/opt/conda/lib", "-lhdf5", "-Wl,-rpath,/opt/conda/lib"])
+        bad, pairs = [], 0
+        chunk = None
+        for tile_row in sorted({j // 4096 for j in cols}):
+            mine = [(k, j) for k, j in enumerate(cols) if j // 4096 == tile_row]
+            tiles = max(j for _, j in mine) // 4096 + 1
+            raw = scratch / "tiles.bin"
+            dims = subprocess.run([str(reader), str(out), str(tile_row), str(tiles), str(raw)], capture_output=True, text=True, timeout=900)
+            assert dims.returncode == 0, dims.stdout + dims.stderr
+            chunk = int(dims.stdout.split()[0])
+            assert chunk == 4096
+            blob = raw.read_bytes()
+            at = 0
+            strips = []  # the pinned rows of every tile of this tile row
+            for c in range(tiles):
+                size = int(np.frombuffer(blob, "<u8", 1, at)[0])
+                stored = blob[at + 8:at + 8 + size]
+                at += 8 + size
+                tile = np.frombuffer(zlib.decompress(stored) if name == "cfg5" else stored, "<i4").reshape(chunk, chunk)
+                strips.append(tile[[j - tile_row * chunk for _, j in mine]].copy())
+                print(f"{name}: tile ({tile_row}, {c}) read back", flush=True)
+            rows = np.concatenate(strips, axis=1)
+            for t, (k, j) in enumerate(mine):
+                col = rows[t, :j]
+                got = (int(col.sum(dtype=np.int64)), int(np.bitwise_xor.reduce(col)), zlib.crc32(np.ascontiguousarray(col, "<i4").tobytes()))
+                want = (int(z["sum"][k]), int(z["xor"][k]), int(z["crc32"][k]))
+                if got != want:
+                    bad.append((j, got, want))
+                assert rows[t, j] == 0  # the diagonal is written as 0
+                pairs += j
+        assert not bad, f"{name} through the tool: {len(bad)} of {len(cols)} pinned columns differ from the reference, first: {bad[0]}"
+        assert pairs > 8_000_000 and n == meta["n"]
+    finally:
+        for p in scratch.glob("*"):
+            p.unlink()
+        scratch.rmdir()
