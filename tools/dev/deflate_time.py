@@ -8,7 +8,7 @@ import zlib
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", ".."))
 import sequencealigner_amd as sa  # noqa: E402
 from tests.synth import make_protein_set  # noqa: E402
 
