@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SA_ABI_VERSION 3
+#define SA_ABI_VERSION 4 /* 4: the sa_zjob_* / sa_hip_tiles_begin entry points */
 
 /* ---- data types shared with the reference ------------------------------- */
 

@@ -34,7 +34,6 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
-#include <cstdlib>
 #include <vector>
 
 #include "sa_ctx.h"
@@ -510,6 +509,7 @@ struct sa_zjob {
 	size_t h_cap[2] = {};
 	size_t host_estimate = 0; /* bytes of the largest batch to come, as far as known */
 	bool two_buffers = false;
+	bool trace = false; /* SA_HIP_ZTRACE (sa_env.h) */
 	/* ONE in-order stream carries the alignment's launches and the encoder's kernels -- the alignment's persistent workgroups
 	 * fill every CU for the whole of a launch (all VGPRs at four waves per SIMD, or all LDS), so on a stream of its own the
 	 * encoder only ever ran when a launch drained, a column block late; in order it runs between two launches, alone, for a few
@@ -636,7 +636,7 @@ static bool zjob_align_block(sa_zjob *z, int32_t blk)
 	if (end > start && sa_ctx_align_range(z->ctx, start, end - start, z->d_owned + start, z->stream) != 0)
 		return false;
 	SA_HIP_CHECK(hipEventRecord(z->block_done[(size_t)blk], z->stream), return false);
-	if (getenv("SA_HIP_ZTRACE"))
+	if (z->trace)
 		fprintf(stderr, "[zjob] block %d: %lld pairs launched in %.2f ms of host time\n", blk, (long long)(end - start), sa_ms_since(t0));
 	return true;
 }
@@ -719,6 +719,7 @@ static sa_zjob *zjob_make(int device, const int32_t *d_packed, const int32_t *d_
 		return nullptr;
 	sa_zjob *z = new sa_zjob;
 	z->device = device;
+	z->trace = sa_env_read().ztrace;
 	z->num = num;
 	z->chunk = (int32_t)chunk_dim;
 	z->chunk_shift = shift;
@@ -846,7 +847,7 @@ static int zjob_fetch(sa_zjob *z, int64_t id, const uint8_t **streams, size_t *s
 	z->raw_bytes += (uint64_t)b.nt * (uint64_t)z->chunk * (uint64_t)z->chunk * 4u;
 	z->copy_ms += sa_ms_since(t1);
 	z->copy_enqueued = -1;
-	if (getenv("SA_HIP_ZTRACE"))
+	if (z->trace)
 		fprintf(stderr, "[zjob] batch %lld (%d tiles, block %d): waited %.2f ms, copy %.2f ms, %zu bytes\n", (long long)id, b.nt, b.block,
 			std::chrono::duration<double, std::milli>(t1 - t0).count(), sa_ms_since(t1), total);
 	/* ---- what runs while the caller writes this batch ---- */

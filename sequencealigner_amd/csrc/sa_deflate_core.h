@@ -51,7 +51,6 @@ struct SaZWork {
 	uint8_t seq[320], seqx[320]; /* header: code-length symbols and their extra bits */
 	uint32_t nseq;
 	uint32_t used;              /* literal alphabet: symbols in use (kernel: after the parallel sort) */
-	unsigned long long s1, s2;  /* Adler-32 partial sums of the segment (kernel)                      */
 };
 
 /* bit writer of the one thread that writes the block header and the block's end (LSB first; the words are zero before) */

@@ -38,5 +38,6 @@ SaEnv sa_env_read()
 	e.verbose = flag("SA_HIP_VERBOSE");
 	e.stamps = flag("SA_HIP_STAMPS");
 	e.stamps_dump = getenv("SA_HIP_STAMPS_DUMP");
+	e.ztrace = flag("SA_HIP_ZTRACE");
 	return e;
 }

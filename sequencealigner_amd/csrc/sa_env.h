@@ -35,6 +35,7 @@ struct SaEnv {
 	bool verbose = false;             /* SA_HIP_VERBOSE                                                               */
 	bool stamps = false;              /* SA_HIP_STAMPS : per-tile clocks of every launch (synchronous)                */
 	const char *stamps_dump = nullptr; /* SA_HIP_STAMPS_DUMP=<file> : raw stamp words                                 */
+	bool ztrace = false;              /* SA_HIP_ZTRACE : the tile walk (sa_deflate.hip) prints what every block / batch cost  */
 };
 
 /* a fresh snapshot of the process environment */

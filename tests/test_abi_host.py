@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(sa):
     for sym in declared:
         assert hasattr(lib, sym), f"{sym} declared in include/seqalign_hip.h but not exported"
     assert sorted(ABI_SYMBOLS) == declared
-    assert lib.sa_abi_version() == 3
+    assert lib.sa_abi_version() == 4
 
 
 def test_product_library_does_not_link_the_oracle():
