@@ -379,7 +379,11 @@ def hip_align(store: SequenceStore, scoring: Scoring, triangular: bool = False, 
     n = store.num
     matrix = None
     if write:
-        matrix = np.zeros(pair_count(n) if triangular else n * n, dtype=np.int32)  # mmap zero-fill, output.c:55
+        # an anonymous zero-filled mapping like output_load's (output.c:55) -- page-aligned and not malloc's, so the library may
+        # page-lock it for the call (it never locks memory malloc manages: DESIGN.md 9)
+        import mmap
+        elements = pair_count(n) if triangular else n * n
+        matrix = np.frombuffer(mmap.mmap(-1, 4 * max(elements, 1)), dtype=np.int32)[:elements]
     out = _Output(matrix.ctypes.data if matrix is not None else None, None, n, bool(triangular))
     sc = scoring._as_c()
     if not lib.sa_hip_align(store._as_c(), out, C.byref(sc)):
@@ -405,7 +409,11 @@ class PinnedMatrix:
                     f.truncate(4 * max(int(elements), 1))
             self.array = np.memmap(shared, dtype=np.int32, mode="r+", shape=(max(int(elements), 1),))[:int(elements)]
         else:
-            self.array = np.zeros(max(int(elements), 1), dtype=np.int32)[:int(elements)]
+            # an anonymous mapping of its own, never malloc's heap: the library refuses to page-lock memory that malloc hands
+            # out again, and a C host's matrix is a mapping anyway (output_load, src/io/output.c:55)
+            import mmap
+            self._map = mmap.mmap(-1, 4 * max(int(elements), 1))
+            self.array = np.frombuffer(self._map, dtype=np.int32)[:int(elements)]
         self.path = shared
         self._registered = False
         if elements and self._lib.sa_hip_host_register(C.c_void_p(self.array.ctypes.data), self.array.nbytes):

@@ -271,7 +271,7 @@ static bool align_slices(struct sa_input in, struct sa_output out, const struct 
 		const size_t n = (size_t)in.num;
 		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)pairs : n * n);
 		const size_t avail = sa_host_available_bytes();
-		if (!sa_host_range_is_pinned(out.matrix, bytes) && (!avail || bytes <= avail / 2)) {
+		if (!sa_host_range_is_pinned(out.matrix, bytes) && (!avail || bytes <= avail / 2) && !sa_host_range_in_malloc_heap(out.matrix, bytes)) {
 			const auto t_pin = std::chrono::steady_clock::now();
 			if (hipHostRegister(out.matrix, bytes, hipHostRegisterPortable) == hipSuccess)
 				pin.p = out.matrix;

@@ -162,6 +162,8 @@ void sa_deliver_release(sa_ctx *ctx);
  * registered in pieces with a hole between them must not take the direct-store path: a GPU page fault, not a fallback.) */
 bool sa_host_range_is_pinned(const void *p, size_t bytes);
 size_t sa_host_available_bytes();
+/* does the range touch the malloc heap ([heap])?  Such memory is never page-locked here */
+bool sa_host_range_in_malloc_heap(const void *p, size_t bytes);
 
 /* sa_abi.hip: progress side channel (sa_hip_set_progress) */
 bool sa_progress_wanted();          /* a callback is set and this thread speaks for the job */

@@ -54,6 +54,36 @@ bool sa_host_range_is_pinned(const void *p, size_t bytes)
 	return byte_is_pinned(hi - 1);
 }
 
+/* May [p, p + bytes) be memory that malloc manages?  It is when it touches the brk segment ("[heap]" in /proc/self/maps), and it
+ * is taken to be when it does not start on a page boundary: a mapping of the caller's own does (output_load's mmap,
+ * src/io/output.c:55), a malloc block never does -- neither one in the heap, nor one malloc mapped by itself (16 bytes of header
+ * in front), nor one in a heap extension that malloc mapped because brk was blocked (no "[heap]" label there).  Such a range is
+ * never page-locked by this library: registering and unregistering memory that malloc goes on to hand out again is the one thing
+ * both GPU memory faults on record have in common -- a fault address inside the heap, hit later by a pageable copy of the
+ * runtime.  A destination there is served through the library's own pinned staging buffers. */
+bool sa_host_range_in_malloc_heap(const void *p, size_t bytes)
+{
+	if (!p || !bytes)
+		return false;
+	if (reinterpret_cast<uintptr_t>(p) % 4096u != 0)
+		return true;
+	FILE *f = fopen("/proc/self/maps", "r");
+	if (!f)
+		return false;
+	const uintptr_t lo = reinterpret_cast<uintptr_t>(p), hi = lo + bytes;
+	bool hit = false;
+	char line[512];
+	while (fgets(line, sizeof(line), f)) {
+		if (!strstr(line, "[heap]"))
+			continue;
+		unsigned long long a = 0, b = 0;
+		if (sscanf(line, "%llx-%llx", &a, &b) == 2 && lo < (uintptr_t)b && hi > (uintptr_t)a)
+			hit = true;
+	}
+	fclose(f);
+	return hit;
+}
+
 /* some of [p, p + bytes) is page-locked, but not the range as one registration (pieces, a hole, a registration that ends
  * inside it): the runtime refuses a copy that crosses a registration boundary, and the range cannot be registered as a
  * whole either -- such a destination is filled by the host from the library's own pinned staging buffers */
@@ -316,6 +346,11 @@ extern "C" int sa_hip_host_register(void *p, size_t bytes)
 		sa_set_error("No HIP devices available; libseqalign_hip has no CPU fallback");
 		return 1;
 	}
+	if (sa_host_range_in_malloc_heap(p, bytes)) {
+		sa_set_error("sa_hip_host_register: the range lies in the malloc heap or does not start on a page boundary; memory that malloc "
+			     "manages is not page-locked (allocate the matrix with mmap, as output_load does: src/io/output.c:55)");
+		return 1;
+	}
 	SA_HIP_CHECK(hipHostRegister(p, bytes, hipHostRegisterPortable), return 1);
 	return 0;
 }
@@ -379,7 +414,7 @@ static int align_host_impl(sa_ctx *ctx, int64_t start, int64_t count, struct sa_
 		int32_t *base = out.triangular ? out.matrix + start : out.matrix;
 		const size_t bytes = sizeof(int32_t) * (out.triangular ? (size_t)total : dim * dim);
 		const size_t avail = sa_host_available_bytes();
-		if (!sa_host_range_is_pinned(base, bytes) && (!avail || bytes <= avail / 2)) {
+		if (!sa_host_range_is_pinned(base, bytes) && (!avail || bytes <= avail / 2) && !sa_host_range_in_malloc_heap(base, bytes)) {
 			const auto t_pin = std::chrono::steady_clock::now();
 			if (hipHostRegister(base, bytes, hipHostRegisterDefault) == hipSuccess)
 				pinned_here = base;

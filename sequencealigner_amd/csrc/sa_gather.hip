@@ -190,7 +190,8 @@ bool sa_align_gathered(struct sa_input in, struct sa_output out, const struct sa
 		(void)hipSetDevice(devices[0]);
 		if (!sa_host_range_is_pinned(out.matrix, bytes)) {
 			const size_t avail = sa_host_available_bytes();
-			if ((!avail || bytes <= avail / 2) && hipHostRegister(out.matrix, bytes, hipHostRegisterPortable) == hipSuccess)
+			if ((!avail || bytes <= avail / 2) && !sa_host_range_in_malloc_heap(out.matrix, bytes) &&
+			    hipHostRegister(out.matrix, bytes, hipHostRegisterPortable) == hipSuccess)
 				job.pinned_here = out.matrix;
 			else
 				(void)hipGetLastError();

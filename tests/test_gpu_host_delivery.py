@@ -168,12 +168,15 @@ def test_destination_registered_in_pieces_with_a_hole_is_not_stored_into_directl
     scoring = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
     lib = sa.load_library()
     page = 4096
-    raw = np.zeros(store.pairs + 2 * page, np.int32)
+    import mmap
+    backing = mmap.mmap(-1, 4 * (store.pairs + 2 * page))  # (a mapping of its own: the library refuses to page-lock malloc's heap)
+    raw = np.frombuffer(backing, np.int32)
     start = (-raw.ctypes.data) % page // 4  # a page-aligned window inside the buffer
     matrix = raw[start:start + store.pairs]
     nbytes = matrix.nbytes
     third = nbytes // 3 // page * page
-    head, tail = matrix.ctypes.data, matrix.ctypes.data + nbytes - third
+    tail_off = (nbytes - third) // page * page  # (both pieces start on a page boundary: the library locks nothing else)
+    head, tail = matrix.ctypes.data, matrix.ctypes.data + tail_off
     assert lib.sa_hip_host_register(C.c_void_p(head), third) == 0
     assert lib.sa_hip_host_register(C.c_void_p(tail), third) == 0
     try:
@@ -181,9 +184,42 @@ def test_destination_registered_in_pieces_with_a_hole_is_not_stored_into_directl
             ctx.align_host(matrix, triangular=True)
         idx = np.sort(np.random.default_rng(5).integers(0, store.pairs, 30000))
         assert np.array_equal(matrix[idx], oracle.align_pairs(store, scoring, idx, threads=16))
-        lo, hi = third // 4 - 1000, (nbytes - third) // 4 + 1000  # across both edges of the hole
+        lo, hi = third // 4 - 1000, tail_off // 4 + 1000  # across both edges of the hole
         assert np.array_equal(matrix[lo:lo + 2000], oracle.align_range(store, scoring, lo, 2000))
         assert np.array_equal(matrix[hi - 2000:hi], oracle.align_range(store, scoring, hi - 2000, 2000))
     finally:
         lib.sa_hip_host_unregister(C.c_void_p(head))
         lib.sa_hip_host_unregister(C.c_void_p(tail))
+
+
+def test_memory_of_the_malloc_heap_is_never_page_locked(sa, oracle):
+    """both GPU memory faults on record hit an address inside the process's brk heap.  The library no longer
+    registers such memory -- sa_hip_host_register refuses it, and a destination there is delivered through the staging
+    buffers (same scores)."""
+    import ctypes as C
+    from tests.synth import make_protein_set
+    lib = sa.load_library()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    store = sa.SequenceStore.from_sequences(make_protein_set(150, 30, 90, 77))
+    scoring = sa.Scoring.from_names("nw", "blosum62", gap_pen=4)
+    nbytes = 4 * store.pairs  # 44 700 bytes: below every mmap threshold, so malloc serves it from the heap
+    p = libc.malloc(nbytes)
+    try:
+        # (late in a long-lived process malloc may serve it from a heap extension it mapped itself, without the "[heap]" label:
+        # either way the block does not start on a page boundary, which is what the library goes by for those)
+        assert p % 4096 != 0
+        assert lib.sa_hip_host_register(C.c_void_p(p), nbytes) != 0
+        page = (p + 4095) // 4096 * 4096  # ... and a page-aligned piece of the heap proper is refused by its address
+        heap = [tuple(int(x, 16) for x in ln.split()[0].split("-")) for ln in open("/proc/self/maps") if "[heap]" in ln]
+        if any(lo <= page and page + 4096 <= hi for lo, hi in heap) and page + 4096 <= p + nbytes:
+            assert lib.sa_hip_host_register(C.c_void_p(page), 4096) != 0
+        assert "malloc heap" in sa.binding._err()
+        matrix = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int32)), shape=(store.pairs,))
+        with sa.Context(store, scoring, 0) as ctx:
+            ctx.align_host(matrix, triangular=True)
+        assert np.array_equal(matrix, oracle.align(store, scoring, triangular=True))
+    finally:
+        libc.free(p)
