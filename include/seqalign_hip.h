@@ -148,7 +148,11 @@ int sa_ctx_align_host(sa_ctx *ctx, int64_t start, int64_t count, struct sa_outpu
 
 /* Page-locks / releases a host range for device->host DMA (hipHostRegister).  A host that allocates its result
  * matrix once (output_load, src/io/output.c:55) registers it there; sa_ctx_align_host / sa_hip_align detect a
- * registered destination and skip their own temporary registration.  0 on success. */
+ * registered destination and skip their own temporary registration.  0 on success.  The range must be a mapping of
+ * the caller's own -- start on a page boundary, outside the malloc heap, as output_load's mmap does: memory that malloc
+ * manages is refused here and never page-locked by the library itself (a destination there is filled through the library's
+ * pinned staging buffers); page-locking blocks that share pages with their heap neighbours is what both GPU memory faults
+ * on this project's record have in common. */
 int sa_hip_host_register(void *p, size_t bytes);
 int sa_hip_host_unregister(void *p);
 
