@@ -210,11 +210,14 @@ int sa_ctx_expand_full(sa_ctx *ctx, const int32_t *d_packed, int32_t *d_full, vo
  *   sa_zjob_create       buffers for one line of tiles; chunk_dim: a power of two in [64, 4096] (sa_host_hdf5_chunk_dim)
  *   sa_zjob_tile_row     streams[t] / sizes[t] for the tiles_per_row tiles of row `tile_row`, valid until the next call;
  *                        rows are asked for in order, each once: the next row is encoded while the caller writes
- *   sa_hip_tiles_begin   sa_ctx_create + the packed matrix in device memory + a job on device 0 that walks the tiles in
+ *   sa_hip_tiles_begin   sa_ctx_create + the packed matrix in device memory + a job that walks the tiles in
  *                        SHELLS while the alignment is still running: the tiles whose larger tile index is b need exactly
  *                        the columns [b * chunk_dim, (b + 1) * chunk_dim), so they are encoded and handed out while the
  *                        device aligns the next column blocks (the alignment phase and the reference's output phase,
- *                        src/main.c:31-34, overlap).  The first blocks are on their way when it returns.
+ *                        src/main.c:31-34, overlap).  The first blocks are on their way when it returns.  With several
+ *                        devices (all visible ones, or the first SA_HIP_DEVICES) block b and its shell belong to device
+ *                        b mod n: a shell needs nothing but its own block, so the devices exchange nothing and every one
+ *                        drives its own PCIe link; the shells still come in ascending order.
  *   sa_zjob_next         the next batch of finished tiles (at most tiles_per_row): rows[t], cols[t] = tile coordinates,
  *                        streams[t] / sizes[t] valid until the next call; returns their number, 0 when every tile has been
  *                        handed out, < 0 on error.  Works on a sa_zjob_create job as well (then: row after row).

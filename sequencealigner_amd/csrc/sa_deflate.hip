@@ -486,8 +486,11 @@ __global__ __launch_bounds__(ZT) void sa_k_tiles_raw(SaZArgs A)
  * the device aligns block b + 1:  batch 2 b - 1 = (b, 0) .. (b, b),  batch 2 b = (0, b) .. (b - 1, b)  (b = 0: the tile (0, 0)). */
 struct SaZBatch {
 	int32_t r0 = 0, c0 = 0, dr = 0, dc = 0, nt = 0;
-	int32_t block = -1; /* the column block whose alignment it waits for (-1: none) */
+	int32_t block = -1; /* the column block whose alignment it waits for, as an index into the job's own blocks (-1: none) */
 };
+/* Several devices: column block b -- its alignment and both arms of its shell -- belongs to device b mod n.  A shell needs
+ * nothing but its own block, so the devices never exchange a byte: the pair space shards into independent units and every
+ * device drives its own PCIe link; the caller still gets the shells in ascending order, from the devices in turn. */
 
 struct sa_zjob {
 	int device = 0;
@@ -521,9 +524,15 @@ struct sa_zjob {
 	size_t copy_bytes = 0;      /* bytes of it that the enqueued copy covers                    */
 	/* shells: the alignment runs block by block, one to two blocks ahead of the encoder */
 	bool shells = false;
-	std::vector<hipEvent_t> block_start, block_done;
+	std::vector<int32_t> own_blocks;   /* the column blocks of this job (this device), ascending */
+	std::vector<SaZBatch> batches;     /* their arms, in the order they are handed out            */
+	std::vector<hipEvent_t> block_start, block_done; /* [own block] */
 	int32_t blocks_launched = 0;
 	int64_t next_batch = 0;
+	/* the job the caller holds, with several devices: the other devices' jobs and whose turn it is */
+	std::vector<sa_zjob *> peers;
+	std::vector<std::pair<int32_t, int64_t>> order; /* (0: this job, k: peers[k - 1]; batch of that job) */
+	size_t order_next = 0;
 	double encode_ms = 0, copy_ms = 0;
 	uint64_t raw_bytes = 0, out_bytes = 0, late_bytes = 0;
 };
@@ -532,6 +541,9 @@ static void zjob_free(sa_zjob *z)
 {
 	if (!z)
 		return;
+	for (sa_zjob *p : z->peers)
+		zjob_free(p);
+	z->peers.clear();
 	(void)hipSetDevice(z->device);
 	for (hipStream_t st : { z->copy_stream, z->stream })
 		if (st) {
@@ -567,20 +579,29 @@ static void zjob_free(sa_zjob *z)
 
 static SaZBatch zjob_batch(const sa_zjob *z, int64_t id)
 {
-	SaZBatch b;
-	if (!z->shells) { /* tile row `id` */
-		b.r0 = (int32_t)id, b.dc = 1, b.nt = z->nc;
-		return b;
-	}
-	const int32_t blk = (int32_t)((id + 1) / 2);
-	b.block = blk;
-	if (id == 0 || (id & 1)) /* the row arm, diagonal tile included */
-		b.r0 = blk, b.dc = 1, b.nt = blk + 1;
-	else                     /* the column arm */
-		b.c0 = blk, b.dr = 1, b.nt = blk;
+	if (z->shells)
+		return z->batches[(size_t)id];
+	SaZBatch b; /* tile row `id` */
+	b.r0 = (int32_t)id, b.dc = 1, b.nt = z->nc;
 	return b;
 }
-static int64_t zjob_batches(const sa_zjob *z) { return z->shells ? 2 * (int64_t)z->nc - 1 : (int64_t)z->nc; }
+static int64_t zjob_batches(const sa_zjob *z) { return z->shells ? (int64_t)z->batches.size() : (int64_t)z->nc; }
+/* the arms of the job's own column blocks: (b, 0) .. (b, b), then (0, b) .. (b - 1, b) */
+static void zjob_plan_shells(sa_zjob *z)
+{
+	z->batches.clear();
+	for (size_t k = 0; k < z->own_blocks.size(); k++) {
+		const int32_t blk = z->own_blocks[k];
+		SaZBatch row;
+		row.block = (int32_t)k, row.r0 = blk, row.dc = 1, row.nt = blk + 1;
+		z->batches.push_back(row);
+		if (blk > 0) {
+			SaZBatch col;
+			col.block = (int32_t)k, col.c0 = blk, col.dr = 1, col.nt = blk;
+			z->batches.push_back(col);
+		}
+	}
+}
 
 static SaZArgs zjob_args(const sa_zjob *z, const SaZBatch &b, int par)
 {
@@ -627,22 +648,23 @@ static bool zjob_host_buffer(sa_zjob *z, int which, size_t bytes)
 }
 
 /* the alignment of column block `blk` (columns [blk * chunk, (blk + 1) * chunk)): one packed range, onto the stream */
-static bool zjob_align_block(sa_zjob *z, int32_t blk)
+static bool zjob_align_block(sa_zjob *z, int32_t own)
 {
+	const int32_t blk = z->own_blocks[(size_t)own];
 	const int64_t ja = (int64_t)blk * z->chunk, jb = std::min<int64_t>((int64_t)z->num, ja + z->chunk);
 	const int64_t start = ja * (ja - 1) / 2, end = jb * (jb - 1) / 2;
 	const auto t0 = std::chrono::steady_clock::now();
-	SA_HIP_CHECK(hipEventRecord(z->block_start[(size_t)blk], z->stream), return false);
+	SA_HIP_CHECK(hipEventRecord(z->block_start[(size_t)own], z->stream), return false);
 	if (end > start && sa_ctx_align_range(z->ctx, start, end - start, z->d_owned + start, z->stream) != 0)
 		return false;
-	SA_HIP_CHECK(hipEventRecord(z->block_done[(size_t)blk], z->stream), return false);
+	SA_HIP_CHECK(hipEventRecord(z->block_done[(size_t)own], z->stream), return false);
 	if (z->trace)
 		fprintf(stderr, "[zjob] block %d: %lld pairs launched in %.2f ms of host time\n", blk, (long long)(end - start), sa_ms_since(t0));
 	return true;
 }
-static bool zjob_align_upto(sa_zjob *z, int32_t blk)
+static bool zjob_align_upto(sa_zjob *z, int32_t own)
 {
-	while (z->blocks_launched < z->nc && z->blocks_launched <= blk) {
+	while (z->blocks_launched < (int32_t)z->own_blocks.size() && z->blocks_launched <= own) {
 		if (!zjob_align_block(z, z->blocks_launched))
 			return false;
 		z->blocks_launched++;
@@ -908,17 +930,29 @@ extern "C" int sa_zjob_next(sa_zjob *z, uint32_t *rows, uint32_t *cols, const ui
 			sa_set_error("sa_zjob_next: bad arguments");
 			return -1;
 		}
-		if (z->next_batch >= zjob_batches(z))
+		sa_zjob *job = z;
+		int64_t id = z->next_batch;
+		if (!z->order.empty()) { /* several devices: the shells in ascending order, from the devices in turn */
+			if (z->order_next >= z->order.size())
+				return 0;
+			const auto &turn = z->order[z->order_next];
+			job = turn.first == 0 ? z : z->peers[(size_t)turn.first - 1];
+			id = turn.second;
+		} else if (id >= zjob_batches(z)) {
 			return 0;
-		const SaZBatch b = zjob_batch(z, z->next_batch);
-		const int n = zjob_fetch(z, z->next_batch, streams, sizes);
+		}
+		const SaZBatch b = zjob_batch(job, id);
+		const int n = zjob_fetch(job, id, streams, sizes);
 		if (n < 0)
 			return -1;
 		for (int t = 0; t < n; t++) {
 			rows[t] = (uint32_t)(b.r0 + t * b.dr);
 			cols[t] = (uint32_t)(b.c0 + t * b.dc);
 		}
-		z->next_batch++;
+		if (!z->order.empty())
+			z->order_next++;
+		else
+			z->next_batch++;
 		return n;
 	});
 }
@@ -927,78 +961,133 @@ extern "C" void sa_zjob_stats(const sa_zjob *z, double *encode_ms, double *copy_
 {
 	if (!z)
 		return;
+	double e = z->encode_ms, c = z->copy_ms;
+	uint64_t r = z->raw_bytes, o = z->out_bytes;
+	for (const sa_zjob *p : z->peers)
+		e += p->encode_ms, c += p->copy_ms, r += p->raw_bytes, o += p->out_bytes;
 	if (encode_ms)
-		*encode_ms = z->encode_ms;
+		*encode_ms = e;
 	if (copy_ms)
-		*copy_ms = z->copy_ms;
+		*copy_ms = c;
 	if (raw_bytes)
-		*raw_bytes = z->raw_bytes;
+		*raw_bytes = r;
 	if (out_bytes)
-		*out_bytes = z->out_bytes;
+		*out_bytes = o;
 }
 
-/* seconds the device spent aligning so far: the sum over the column blocks whose kernels have finished */
+static double zjob_align_ms(const sa_zjob *z)
+{
+	double ms = 0.0;
+	for (int32_t k = 0; k < z->blocks_launched; k++) {
+		float one = 0.f;
+		if (hipEventElapsedTime(&one, z->block_start[(size_t)k], z->block_done[(size_t)k]) == hipSuccess)
+			ms += one;
+	}
+	(void)hipGetLastError();
+	return ms;
+}
+
+/* seconds the device spent aligning so far: the sum over the column blocks whose kernels have finished; several devices
+ * align side by side: the longest of their sums */
 extern "C" double sa_zjob_align_seconds(const sa_zjob *z)
 {
 	return sa_guard("sa_zjob_align_seconds", 0.0, [&]() -> double {
 		if (!z || !z->shells)
 			return 0.0;
-		double ms = 0.0;
-		for (int32_t k = 0; k < z->blocks_launched; k++) {
-			float one = 0.f;
-			if (hipEventElapsedTime(&one, z->block_start[(size_t)k], z->block_done[(size_t)k]) == hipSuccess)
-				ms += one;
+		(void)hipSetDevice(z->device);
+		double ms = zjob_align_ms(z);
+		for (const sa_zjob *p : z->peers) {
+			(void)hipSetDevice(p->device);
+			ms = std::max(ms, zjob_align_ms(p));
 		}
-		(void)hipGetLastError();
 		return ms * 1e-3;
 	});
 }
 
-/* Context + the packed matrix in device memory + a job that walks it in shells while the alignment runs (see SaZBatch): the
- * first column blocks are on their way when this returns. */
+/* one device's part of a walk in shells: context, the packed matrix (whole: a block's place in it is its own), a job over
+ * the column blocks `first`, `first + step`, ...; the first two of them are on their way when this returns */
+static sa_zjob *zjob_begin_on(int device, struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, bool stored, int first, int step)
+{
+	sa_ctx *ctx = sa_ctx_create(device, in, sc);
+	if (!ctx)
+		return nullptr;
+	int32_t *d_packed = nullptr;
+	sa_zjob *z = nullptr;
+	bool ok = false;
+	do {
+		const int64_t pairs = sa_ctx_pairs(ctx);
+		SA_HIP_CHECK(hipSetDevice(device), break);
+		SA_HIP_CHECK(hipMalloc(&d_packed, sizeof(int32_t) * (size_t)pairs), break);
+		z = zjob_make(device, d_packed, nullptr, in.num, chunk_dim, stored);
+		if (!z)
+			break;
+		z->shells = true;
+		for (int32_t b = first; b < z->nc; b += step)
+			z->own_blocks.push_back(b);
+		zjob_plan_shells(z);
+		z->block_start.assign(z->own_blocks.size(), nullptr);
+		z->block_done.assign(z->own_blocks.size(), nullptr);
+		bool ev = true;
+		for (size_t k = 0; k < z->own_blocks.size() && ev; k++)
+			ev = hipEventCreate(&z->block_start[k]) == hipSuccess && hipEventCreate(&z->block_done[k]) == hipSuccess;
+		if (!ev) {
+			sa_set_error("sa_hip_tiles_begin: hipEventCreate failed");
+			break;
+		}
+		ok = true;
+	} while (0);
+	if (z) { /* (the job owns context and matrix from here on, whatever happens) */
+		z->d_owned = d_packed;
+		z->ctx = ctx;
+	}
+	/* the alignment starts now: the first blocks are small, the caller's file set-up runs beside them */
+	if (ok)
+		ok = zjob_align_upto(z, 1);
+	if (!ok) {
+		if (z)
+			zjob_free(z);
+		else {
+			(void)hipFree(d_packed);
+			sa_ctx_destroy(ctx);
+		}
+		return nullptr;
+	}
+	return z;
+}
+
+/* Context(s) + the packed matrix in device memory + a job that walks it in shells while the alignment runs (see SaZBatch).
+ * Every device in use (all visible ones, or the first SA_HIP_DEVICES) takes the column blocks b = device (mod devices);
+ * SA_HIP_TILES_SPLIT=n (testing) makes n such jobs share device 0. */
 extern "C" sa_zjob *sa_hip_tiles_begin(struct sa_input in, const struct sa_scoring *sc, size_t chunk_dim, int level)
 {
 	return sa_guard("sa_hip_tiles_begin", (sa_zjob *)nullptr, [&]() -> sa_zjob * {
-		sa_ctx *ctx = sa_ctx_create(0, in, sc);
-		if (!ctx)
+		const SaEnv env = sa_env_read();
+		int parts = sa_devices_in_use(env);
+		if (parts <= 0) {
+			sa_set_error("No HIP devices available; libseqalign_hip has no CPU fallback");
 			return nullptr;
-		int32_t *d_packed = nullptr;
-		sa_zjob *z = nullptr;
-		bool ok = false;
-		do {
-			const int64_t pairs = sa_ctx_pairs(ctx);
-			SA_HIP_CHECK(hipMalloc(&d_packed, sizeof(int32_t) * (size_t)pairs), break);
-			z = zjob_make(0, d_packed, nullptr, in.num, chunk_dim, level == 0);
-			if (!z)
-				break;
-			z->shells = true;
-			z->block_start.assign((size_t)z->nc, nullptr);
-			z->block_done.assign((size_t)z->nc, nullptr);
-			bool ev = true;
-			for (int32_t k = 0; k < z->nc && ev; k++)
-				ev = hipEventCreate(&z->block_start[(size_t)k]) == hipSuccess && hipEventCreate(&z->block_done[(size_t)k]) == hipSuccess;
-			if (!ev) {
-				sa_set_error("sa_hip_tiles_begin: hipEventCreate failed");
-				break;
-			}
-			ok = true;
-		} while (0);
-		if (z) { /* (the job owns context and matrix from here on, whatever happens) */
-			z->d_owned = d_packed;
-			z->ctx = ctx;
 		}
-		if (ok) {
-			/* the alignment starts now: the first blocks are small, the caller's file set-up runs beside them */
-			ok = zjob_align_upto(z, 1);
-		}
-		if (!ok) {
-			if (z)
+		const bool folded = env.tiles_split > 0;
+		if (folded)
+			parts = env.tiles_split;
+		const int nc = chunk_dim ? (int)(((size_t)in.num + chunk_dim - 1) / chunk_dim) : 1;
+		parts = std::max(1, std::min(parts, nc)); /* (a device without a column block would have nothing to do) */
+		sa_zjob *z = zjob_begin_on(0, in, sc, chunk_dim, level == 0, 0, parts);
+		if (!z)
+			return nullptr;
+		for (int k = 1; k < parts; k++) {
+			sa_zjob *p = zjob_begin_on(folded ? 0 : k, in, sc, chunk_dim, level == 0, k, parts);
+			if (!p) {
 				zjob_free(z);
-			else {
-				(void)hipFree(d_packed);
-				sa_ctx_destroy(ctx);
+				return nullptr;
 			}
-			return nullptr;
+			z->peers.push_back(p);
+		}
+		if (parts > 1) { /* whose turn it is: block b belongs to job b mod parts, its arms follow each other */
+			std::vector<int64_t> at((size_t)parts, 0);
+			for (int32_t b = 0; b < z->nc; b++)
+				for (int arm = 0; arm < (b > 0 ? 2 : 1); arm++)
+					z->order.emplace_back(b % parts, at[(size_t)(b % parts)]++);
 		}
 		return z;
 	});

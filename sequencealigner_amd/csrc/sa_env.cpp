@@ -35,6 +35,7 @@ SaEnv sa_env_read()
 	e.devices = number("SA_HIP_DEVICES", 0, 0, 1024);
 	e.split = number("SA_HIP_SPLIT", 0, 0, 1024);
 	e.gather = getenv("SA_HIP_GATHER") ? (atoi(getenv("SA_HIP_GATHER")) != 0) : -1;
+	e.tiles_split = number("SA_HIP_TILES_SPLIT", 0, 0, 64);
 	e.verbose = flag("SA_HIP_VERBOSE");
 	e.stamps = flag("SA_HIP_STAMPS");
 	e.stamps_dump = getenv("SA_HIP_STAMPS_DUMP");

@@ -31,6 +31,7 @@ struct SaEnv {
 	int devices = 0; /* SA_HIP_DEVICES=n : use the first n visible devices                                           */
 	int split = 0;   /* SA_HIP_SPLIT=n   : n slices even when fewer devices are visible (testing aid)                */
 	int gather = -1; /* SA_HIP_GATHER=0/1: multi-device path through dense shares + RCCL all-gather (-1: default)    */
+	int tiles_split = 0; /* SA_HIP_TILES_SPLIT=n: sa_hip_tiles_begin deals the column blocks over n jobs on device 0 (testing aid) */
 	/* diagnostics */
 	bool verbose = false;             /* SA_HIP_VERBOSE                                                               */
 	bool stamps = false;              /* SA_HIP_STAMPS : per-tile clocks of every launch (synchronous)                */

@@ -158,3 +158,31 @@ def test_shells_while_the_alignment_runs(n, chunk, method, level, sa, oracle):
     assert len(seen) == nc * nc
     for (r, c), got in seen.items():
         assert got == want[r][c], (r, c)
+
+
+@pytest.mark.parametrize("parts,level", [(2, 6), (3, 6), (5, 0), (9, 6)])
+def test_shells_dealt_over_several_jobs(parts, level, sa, oracle, monkeypatch):
+    """sa_hip_tiles_begin with several devices deals the column blocks over them (block b and its shell -> device b mod n; no
+    exchange).  A one-GPU box folds n such jobs onto device 0 (SA_HIP_TILES_SPLIT): the same code, every job with its own
+    context, matrix, streams and buffers; the tiles still arrive shell after shell, every one exactly once."""
+    from tests.synth import make_protein_set
+    n, chunk = 1700, 256  # 7 column blocks: fewer than nine jobs, more than two
+    store = sa.SequenceStore.from_sequences(make_protein_set(n, 20, 70, 5))
+    scoring = sa.Scoring.from_names("ga", "blosum62", gap_open=10, gap_extend=1)
+    full = tri_to_full(oracle.align(store, scoring, triangular=True), n)
+    nc, want = expected_tiles(full, chunk)
+    monkeypatch.setenv("SA_HIP_TILES_SPLIT", str(parts))
+    seen, order = {}, []
+    with sa.DeflateJob.begin(store, scoring, chunk, level=level) as job:
+        while True:
+            batch = job.next()
+            if not batch:
+                break
+            for r, c, z in batch:
+                assert (r, c) not in seen
+                seen[(r, c)] = zlib.decompress(z) if level else z
+                order.append(max(r, c))
+        assert order == sorted(order) and job.align_seconds > 0
+        st = job.stats()
+        assert st["raw_bytes"] == nc * nc * chunk * chunk * 4
+    assert len(seen) == nc * nc and all(seen[k] == want[k[0]][k[1]] for k in seen)
