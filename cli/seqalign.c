@@ -423,8 +423,9 @@ int main(int argc, char **argv)
 	bool device_deflate = !o.no_write && n > 256 && !getenv("SA_HOST_MATRIX") &&
 			      (o.compression > 0 ? !getenv("SA_HOST_CPU_DEFLATE") && !getenv("SA_HOST_SERIAL_DEFLATE")
 						 /* without -z the same walk returns the tiles as they are: H5Dwrite_chunk instead of H5Dwrite's
-						  * gather of every tile out of N-wide rows.  One device only: on several, sa_hip_align's
-						  * all-devices alignment is worth more than the faster writer */
+						  * gather of every tile out of N-wide rows.  On several devices the plain path stays with sa_hip_align
+						  * (tiles dealt by DP work, RCCL all-gather: the whole matrix on every device and in host memory);
+						  * with -z the walk itself runs on all of them (sa_hip_tiles_begin: block b -> device b mod n) */
 						 : sa_hip_device_count() == 1);
 	if (device_deflate) {
 		/* the packed scores + one tile row: raw, or raw + worst-case slots and streams (1 + 2 x 2.02 x the row's raw bytes) */
