@@ -233,7 +233,7 @@ def time_resident_steps(ctx, packed, pairs: int, steps: int, warmup: int, torch)
     return elapsed, tm
 
 
-def cli_leg(seqs, cfg, quiet: bool = True) -> dict | None:
+def cli_leg(seqs, cfg, quiet: bool = True, extra_flags=(), keep_size: bool = False) -> dict | None:
     """The product as a user runs it: `cli/seqalign -i x.fasta -o x.h5 ... -B` from a cold process."""
     exe = ROOT / "cli" / "seqalign"
     if not exe.exists():
@@ -245,10 +245,13 @@ def cli_leg(seqs, cfg, quiet: bool = True) -> dict | None:
                 f.write(b">s%d\n" % k + s + b"\n")
         g = cfg["gaps"]
         gaps = ["-p", str(g["gap_pen"])] if "gap_pen" in g else ["-s", str(g["gap_open"]), "-e", str(g["gap_extend"])]
-        cmd = [str(exe), "-i", str(fasta), "-o", str(pathlib.Path(tmp) / "out.h5"), "-a", cfg["method"], "-m", cfg["matrix"], *gaps, "-B", "-F", *(["-Q"] if quiet else [])]
+        cmd = [str(exe), "-i", str(fasta), "-o", str(pathlib.Path(tmp) / "out.h5"), "-a", cfg["method"], "-m", cfg["matrix"], *gaps,
+               *map(str, extra_flags), "-B", "-F", *(["-Q"] if quiet else [])]
         t0 = time.perf_counter()
         r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         wall = time.perf_counter() - t0
+        out_h5 = pathlib.Path(tmp) / "out.h5"
+        file_bytes = out_h5.stat().st_size if keep_size and out_h5.exists() else None
     txt = r.stdout + r.stderr
     if r.returncode != 0:
         return {"error": txt[-400:], "returncode": r.returncode}
@@ -259,7 +262,7 @@ def cli_leg(seqs, cfg, quiet: bool = True) -> dict | None:
     return {"command": " ".join(["cli/seqalign", *cmd[1:2], "in.fasta", "-o", "out.h5", *cmd[5:]]),
             "alignments_per_second": grab("Alignments per second"), "input_s": grab("Input"), "filter_s": grab("Filter"),
             "alignment_s": grab("Alignment"), "output_s": grab("Output"), "setup_s": grab(r"outside the phases as in the reference"),
-            "process_wall_s": wall,
+            "process_wall_s": wall, **({"file_bytes": file_bytes} if keep_size else {}),
             "note": "cold process, FASTA -> full N x N HDF5, the chunks tiled on the device and written while the next column blocks are "
                     "aligned (DESIGN.md 4.8); alignment = the device's alignment time (reference's bench_align bracket), output = the "
                     "rest of that section, setup = context, code-object load, upload, buffers (outside the phases as in the reference)"}
@@ -370,6 +373,31 @@ def deflate_leg(seqs, cfg, torch, sa) -> dict:
                         "alone: profiles/r04d_deflate_encoder_summary.txt",
                 "parity": {"tiles_inflated": tiles, "elements_compared": tiles * chunk * chunk, "mismatches": mism, "against": against,
                            "compared": "zlib.decompress of every tile vs the full symmetric matrix of the CPU scores (zero diagonal, zero padding)"}})
+    return out
+
+
+def tool_end_to_end_leg(make_config) -> dict:
+    """BASELINE configs 5 and 4 END TO END through the product, at their full size on this one device: cli/seqalign from a cold
+    process, FASTA -> N x N HDF5 (config 5 with its options -f 0.9 -z 6: device filter, alignment in column blocks, the tiles of
+    every shell deflated on the device and written meanwhile; config 4 without -z: raw tiles).  Needs ~25 GB of scratch space
+    for the two 11 GB files (one at a time); skipped without it.  Parity of exactly this path at exactly this size:
+    tests/test_gpu_stripes.py::test_full_size_tool_output_matches_the_reference."""
+    import shutil
+    free = shutil.disk_usage(tempfile.gettempdir()).free
+    if free < 30 * 2**30:
+        return {"skipped": f"{free / 2**30:.0f} GB free under {tempfile.gettempdir()}: needs 30"}
+    out = {}
+    for name, flags in (("cfg5", ["-f", "0.9", "-z", "6"]), ("cfg4", [])):
+        seqs, cfg = make_config(name)
+        leg = cli_leg(seqs, cfg, quiet=True, extra_flags=flags, keep_size=True) or {"error": "cli/seqalign is not built"}
+        leg["sequences_in"] = len(seqs)
+        leg.pop("note", None)
+        if "error" not in leg:
+            leg["total_s"] = sum(leg.get(k) or 0.0 for k in ("input_s", "filter_s", "alignment_s", "output_s"))
+        out[name] = leg
+    out["note"] = ("total_s = the tool's own phases (input + filter + alignment + output; alignment and output overlap: output is what the "
+                   "output section took beyond the device's alignment time); process_wall_s adds loading, device set-up and exit. "
+                   "History of config 5's total: zlib -6 on every core 159.8 s (profiles/r04_cli_cfg5_full_size_end_to_end.txt)")
     return out
 
 
@@ -511,7 +539,9 @@ def main():
                             # the same cfg 2 step with the packed kernels switched off: the reference-width (s32) systolic kernels
                             "s32_kernels": s32_kernels_leg(seqs, cfg, 3, torch, sa),
                             # the -z path: the matrix as HDF5 chunks deflated on the device, every tile inflated and compared
-                            "deflate": deflate_leg(seqs, cfg, torch, sa)}
+                            "deflate": deflate_leg(seqs, cfg, torch, sa),
+                            # BASELINE configs 5 and 4 end to end through the tool at full size (one device)
+                            "tool_end_to_end": tool_end_to_end_leg(make_config)}
         emit(out)
         return
 
